@@ -1,0 +1,207 @@
+"""Pins the CPU oracle (oracle/ddn_oracle.py) to the golden vectors that
+oracle/make_golden.py produced by running the reference implementation itself.
+CPU only.  Tolerances are roundoff-level: the oracle issues the same torch CPU
+ops as the reference, so differences come only from op ordering."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddn_oracle as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_kernels(golden_dir):
+    g = _load(golden_dir, "kernels.npz")
+    assert np.array_equal(O.gaussian_filter([5, 5], 0.8), g["gauss5"])
+    assert np.array_equal(O.gaussian_filter([9, 9], 0.8), g["gauss9"])
+    assert np.array_equal(O.gaussian_filter([10, 10], 0.8), g["gauss10"])
+    assert np.array_equal(O.create_motion_blur_kernel(15, 45).numpy(), g["motion15_45"])
+    assert np.array_equal(O.create_motion_blur_kernel(15, 0).numpy(), g["motion15_0"])
+    assert np.array_equal(O.create_motion_blur_kernel(5, 30).numpy(), g["motion5_30"])
+    assert np.array_equal(O.create_motion_blur_kernel(8, 120).numpy(), g["motion8_120"])
+    assert int((g["motion15_45"] != 0).sum()) == 156  # rotated filled square, not a line
+
+
+def test_eigen_arrays(golden_dir):
+    g = _load(golden_dir, "eigen.npz")
+    k = _load(golden_dir, "kernels.npz")
+    for kname in ["gauss5", "gauss9", "gauss10", "motion15_45", "motion5_30"]:
+        for (H, W) in [(32, 32), (64, 64), (48, 80)]:
+            e = O.eig_vals_for_periodic_conv_op(torch.from_numpy(k[kname]), H, W).numpy()
+            assert e.dtype == np.complex64
+            np.testing.assert_allclose(e, g[f"{kname}_{H}x{W}_K"], rtol=0, atol=2e-7)
+    for (H, W) in [(32, 32), (64, 64), (48, 80)]:
+        for (t, s) in [(1, 1), (2, None), (3, 3)]:
+            op = O.DeblurDenoiseOperators(k["gauss9"], torch.zeros(H, W), t, s)
+            np.testing.assert_allclose(op.eig_vals_mat.numpy(), g[f"gauss9_{H}x{W}_t{t}_s{s}_M"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(op.eig_arry_D1.numpy(), g[f"{H}x{W}_D1"], atol=2e-7)
+        # quirk: D1 and D2 are the same horizontal difference, every row identical
+        assert np.array_equal(g[f"{H}x{W}_D1"], g[f"{H}x{W}_D2"])
+        n = np.arange(W)
+        np.testing.assert_allclose(g[f"{H}x{W}_D1"][3], 1 - np.exp(-2j * np.pi * n / W), atol=5e-7)
+
+
+def test_operator_applications(golden_dir):
+    g = _load(golden_dir, "operators.npz")
+    k = _load(golden_dir, "kernels.npz")
+    for kname in ["gauss9", "motion15_45", "gauss10"]:
+        for (H, W) in [(64, 64), (48, 80)]:
+            tag = f"{kname}_{H}x{W}"
+            x = torch.from_numpy(g[tag + "_x"]); y2 = torch.from_numpy(g[tag + "_y2"])
+            op = O.DeblurDenoiseOperators(k[kname], x, 2.0, 0.5)
+            for nm, val in [("K", op.apply_K(x)), ("KT", op.apply_KTrans(x)), ("D1", op.apply_D1(x)),
+                            ("D1T", op.apply_D1Trans(x)), ("D", op.apply_D(x)), ("DT", op.apply_DTrans(y2)),
+                            ("inv", op.invert_matrix(x)), ("Mat", op.apply_Mat(x))]:
+                np.testing.assert_allclose(val.numpy(), g[f"{tag}_{nm}"], rtol=0, atol=3e-6, err_msg=f"{tag} {nm}")
+            # closed forms used by the HIP kernels: K is a circular correlation centred at k//2,
+            # D is the backward difference along the width
+            kk = k[kname].astype(np.float32)
+            kh, kw = kk.shape
+            xn = g[tag + "_x"].astype(np.float64)
+            ref = np.zeros_like(xn)
+            for u in range(kh):
+                for v in range(kw):
+                    ref += kk[u, v] * np.roll(xn, (-(u - kh // 2), -(v - kw // 2)), (0, 1))
+            np.testing.assert_allclose(g[tag + "_K"].real, ref, atol=3e-6)
+            np.testing.assert_allclose(g[tag + "_D1"].real, xn - np.roll(xn, 1, 1), atol=3e-6)
+            np.testing.assert_allclose(g[tag + "_D1T"].real, xn - np.roll(xn, -1, 1), atol=3e-6)
+
+
+def test_prox(golden_dir):
+    g = _load(golden_dir, "prox.npz")
+    x = torch.from_numpy(g["x"]); x2 = torch.from_numpy(g["x2"])
+    for i in range(3):
+        lam = float(g[f"lam{i}"])
+        assert np.array_equal(O.prox_l1(x, lam).numpy(), g[f"l1_{i}"])
+        np.testing.assert_allclose(O.prox_l2(x, lam).numpy(), g[f"l2_{i}"], rtol=1e-6)
+        assert np.array_equal(O.prox_l2_squared(x, lam).numpy(), g[f"l2sq_{i}"])
+        assert np.array_equal(O.prox_iso(x2, lam).numpy(), g[f"iso_{i}"])
+        assert np.array_equal(O.prox_box(x, lam).numpy(), g[f"box_{i}"])
+    e = torch.from_numpy(g["edge"])
+    assert np.array_equal(O.prox_l1(e, 0.5).numpy(), g["edge_l1"])
+    assert np.array_equal(O.prox_box(e, 0.5).numpy(), g["edge_box"])
+    e2 = torch.from_numpy(g["edge2"])
+    assert np.array_equal(O.prox_iso(e2, 5.0).numpy(), g["edge2_iso5"])
+    assert np.array_equal(O.prox_iso(e2, 0.5).numpy(), g["edge2_iso05"])
+    # strict '>' : norm == lambda maps to zero
+    assert g["edge2_iso5"][0, 0, 1] == 0 and g["edge2_iso5"][1, 0, 3] == 0
+    assert np.array_equal(g["edge_l2_eq"], np.zeros(2, np.float32))
+
+
+def test_circular_convolve(golden_dir):
+    g = _load(golden_dir, "circconv.npz")
+    k = _load(golden_dir, "kernels.npz")
+    for kname in ["gauss9", "gauss10", "motion15_45", "motion5_30"]:
+        for (H, W) in [(32, 32), (48, 80)]:
+            tag = f"{kname}_{H}x{W}"
+            out = O.circular_convolve2d(torch.from_numpy(g[tag + "_img"]), torch.from_numpy(k[kname]))
+            np.testing.assert_allclose(out.numpy(), g[tag + "_out"], atol=1e-6)
+            # pins the (-kh)//2 roll: delta at (3,5) -> kernel tap (u,v) lands at (3+u-ceil(kh/2), 5+v-ceil(kw/2))
+            kk = k[kname].astype(np.float32); kh, kw = kk.shape
+            exp = np.zeros((H, W))
+            for u in range(kh):
+                for v in range(kw):
+                    exp[(3 + u + (-kh // 2)) % H, (5 + v + (-kw // 2)) % W] += kk[u, v]
+            np.testing.assert_allclose(g[tag + "_delta"][0], exp, atol=1e-6)
+
+
+def test_losses(golden_dir):
+    g = _load(golden_dir, "loss.npz")
+    a = torch.from_numpy(g["a"]); b = torch.from_numpy(g["b"])
+    for fn in ["l1_loss", "l2_loss", "mse", "psnr", "ssim"]:
+        np.testing.assert_allclose(np.asarray(getattr(O, fn)(a, b)).reshape(-1), g[fn], rtol=1e-6)
+    assert np.isinf(g["psnr_same"][0]) and np.isinf(float(O.psnr(a, a)))
+
+
+def _t(a, dt):
+    return torch.from_numpy(np.asarray(a)).to(dt)
+
+
+CASES = [("f32", "gauss9", "64x64"), ("f32", "motion15_45", "64x64"), ("f32", "gauss5", "48x80"),
+         ("f64", "gauss9", "64x64"), ("f64", "motion15_45", "64x64")]
+
+
+@pytest.mark.parametrize("dtn,kname,shape", CASES)
+def test_solver_trajectories(golden_dir, dtn, kname, shape):
+    """Faithful restatements reproduce the reference iterates (same torch CPU ops)."""
+    g = _load(golden_dir, f"traj_{dtn}_{kname}_{shape}.npz")
+    dt = torch.float32 if dtn == "f32" else torch.float64
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dt)
+    try:
+        b = _t(g["b"], dt); kern = torch.from_numpy(g["kernel"])
+        tol = 2e-5 if dtn == "f32" else 1e-11
+        Ns = [1, 5, 20] if shape == "48x80" else [1, 5, 20, 100]
+        for N in Ns:
+            st = (_t(g["cp_x0"], dt), _t(g["cp_z0"], dt), _t(g["cp_y0"], dt))
+            x = O.chambolle_pock(b[None], kern, t=0.3, s=0.3, max_iter=N + 1, init_state=st)
+            assert O.rel_l2(x.numpy(), g[f"cpstab_l1_N{N}"]) < tol
+            st = (_t(g["admm_u0"], dt), _t(g["admm_w0"], dt), _t(g["admm_y0"], dt), _t(g["admm_z0"], dt))
+            x = O.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=st)
+            assert O.rel_l2(x.numpy(), g[f"admm_l1_N{N}"]) < tol
+            x = O.primal_dr_splitting("l1", kern, b, niters=N)
+            assert O.rel_l2(x.numpy(), g[f"pdr_l1_N{N}"]) < tol
+            x = O.primal_dr_splitting("l2", kern, b, niters=N)
+            assert O.rel_l2(x.numpy(), g[f"pdr_l2_N{N}"]) < tol
+            st = (_t(g["pddr_p0"], dt), _t(g["pddr_q0"], dt))
+            x = O.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=st)
+            assert O.rel_l2(x.numpy(), g[f"pddr_N{N}"]) < tol
+        # default (unstable) Chambolle-Pock steps: bounded N only
+        st = (_t(g["cp_x0"], dt), _t(g["cp_z0"], dt), _t(g["cp_y0"], dt))
+        x = O.chambolle_pock(b[None], kern, max_iter=21, init_state=st)
+        assert x.shape == (1,) + tuple(b.shape)
+        assert O.rel_l2(x.numpy(), g["cpdef_l1_N20"]) < tol
+        # loss sequence
+        losses = []
+        O.primal_dr_splitting("l1", kern, b, niters=20, loss_function=O.mse, tol=-1.0, losses=losses)
+        # the reference also calls loss_function(z1, b) for logging at j == 0 (twice), j == 15 and once
+        # after the loop (primal_dr/algorithm.py:134-141,165); drop those recorder entries
+        ref = list(g["pdr_l1_N20_mse"])
+        ref = ref[2:15] + ref[16:-1]
+        np.testing.assert_allclose(losses, ref, rtol=1e-4)
+    finally:
+        torch.set_default_dtype(old)
+
+
+def test_rng_replay_matches_reference_init(golden_dir):
+    """torch.manual_seed(7) + the reference's draw order reproduces its initial iterates."""
+    g = _load(golden_dir, "traj_f32_gauss9_64x64.npz")
+    torch.manual_seed(7)
+    assert np.array_equal(torch.rand(64, 64).numpy(), g["cp_x0"])
+    assert np.array_equal(torch.rand(64, 64).numpy(), g["cp_z0"])
+    assert np.array_equal(torch.rand(3, 64, 64).numpy(), g["cp_y0"])
+    torch.manual_seed(7)
+    assert np.array_equal(torch.rand(64, 64).numpy(), g["pddr_p0"])
+    torch.manual_seed(7)
+    d = [torch.clamp(torch.randn((64, 64), dtype=torch.float32), 0, 1) for _ in range(3)]
+    assert np.array_equal(d[1].numpy(), g["admm_u0"]) and np.array_equal(d[2].numpy(), g["admm_w0"])
+
+
+@pytest.mark.parametrize("dtn,kname", [("f32", "gauss9"), ("f32", "motion15_45"), ("f64", "gauss9"), ("f64", "motion15_45")])
+def test_fused_restatement_matches_reference(golden_dir, dtn, kname):
+    """The real-FFT restatement that the HIP kernels implement stays within the
+    stated parity tolerance of the reference iterates (fp32: stencil D, 1e-5;
+    fp64: supplied eigen arrays + row-spectral D, 1e-11)."""
+    g = _load(golden_dir, f"traj_{dtn}_{kname}_64x64.npz")
+    rt = np.float32 if dtn == "f32" else np.float64
+    tol = 1e-5 if dtn == "f32" else 1e-11
+    sd = dtn == "f64"
+    b = g["b"]
+    fo1 = O.FusedOps(g["eigK"], g["eigD"], g["M_t1_s1"], rt)
+    fo2 = O.FusedOps(g["eigK"], g["eigD"], g["M_pdr_t2"], rt)
+    fo3 = O.FusedOps(g["eigK"], g["eigD"], g["M_pddr_t3"], rt)
+    for N in [20, 100, 500]:
+        for prob in ["l1", "l2"]:
+            assert O.rel_l2(O.fused_pdr(fo2, b, prob, N, 0.049, 2.0, 0.1, sd), g[f"pdr_{prob}_N{N}"]) < tol
+            x = O.fused_admm(fo1, b, g["admm_u0"], g["admm_w0"], g["admm_y0"], g["admm_z0"], prob, N + 1, 18, 0.001, 0.5, sd)
+            assert O.rel_l2(x, g[f"admm_{prob}_N{N}"]) < tol
+        assert O.rel_l2(O.fused_pddr(fo3, b, g["pddr_p0"], g["pddr_q0"], N + 1, 3, 0.4, 0.03, sd), g[f"pddr_N{N}"]) < tol
+        x = O.fused_cp(fo1, b, g["cp_x0"], g["cp_z0"], g["cp_y0"], "l1", N + 1, 0.3, 0.3, 0.01, sd)
+        assert O.rel_l2(x, g[f"cpstab_l1_N{N}"][0]) < tol
+    x = O.fused_cp(fo1, b, g["cp_x0"], g["cp_z0"], g["cp_y0"], "l1", 21, 0.4, 0.7, 0.01, sd)
+    assert O.rel_l2(x, g["cpdef_l1_N20"][0]) < tol

@@ -1,0 +1,1081 @@
+// Host side of libddn: plan management, transform factorisation, launch sequencing of the four
+// solver loops, and the extern "C" entry points declared in include/ddn.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/ddn.h"
+#include "ddn_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(DDN_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr size_t kLdsMax = 160 * 1024;
+
+// ------------------------------------------------------------------------------ factorisation
+bool factorize(int n, FftDesc& d) {
+    std::memset(&d, 0, sizeof(d));
+    d.n = n;
+    std::vector<int> rad;
+    int rem = n;
+    int twos = 0;
+    while (rem % 2 == 0) {
+        rem /= 2;
+        ++twos;
+    }
+    // 2^twos as radix 16 / 8 / 4 / 2 passes, larger radices first
+    if (twos > 0) {
+        int a = twos / 4;
+        const int r = twos % 4;
+        if (r == 0) {
+            for (int i = 0; i < a; ++i) rad.push_back(16);
+        } else if (r == 3) {
+            for (int i = 0; i < a; ++i) rad.push_back(16);
+            rad.push_back(8);
+        } else if (r == 2) {
+            if (a >= 1) {
+                for (int i = 0; i < a - 1; ++i) rad.push_back(16);
+                rad.push_back(8);
+                rad.push_back(8);
+            } else {
+                rad.push_back(4);
+            }
+        } else {
+            if (a >= 1) {
+                for (int i = 0; i < a - 1; ++i) rad.push_back(16);
+                rad.push_back(8);
+                rad.push_back(4);
+            } else {
+                rad.push_back(2);
+            }
+        }
+    }
+    const int primes[] = {3, 5, 7, 11, 13};
+    for (int p : primes) {
+        while (rem % p == 0) {
+            rad.push_back(p);
+            rem /= p;
+        }
+    }
+    if (rem != 1) return false;
+    if (rad.empty()) rad.push_back(1);
+    if ((int)rad.size() > DDN_MAXPASS) return false;
+    if (n == 1) {
+        d.npass = 0;
+        d.pow2 = 1;
+        return true;
+    }
+    d.npass = (int)rad.size();
+    d.pow2 = 1;
+    int L = n;
+    for (int s = 0; s < d.npass; ++s) {
+        const int r = rad[s];
+        d.radix[s] = r;
+        d.m[s] = L / r;
+        d.twmul[s] = n / L;
+        int ms = -1;
+        if ((d.m[s] & (d.m[s] - 1)) == 0) {
+            ms = 0;
+            while ((1 << ms) < d.m[s]) ++ms;
+        }
+        d.mshift[s] = ms;
+        if ((r & (r - 1)) == 0) {
+            int rs = 0;
+            while ((1 << rs) < r) ++rs;
+            d.rshift[s] = rs;
+        } else {
+            d.pow2 = 0;
+        }
+        L /= r;
+    }
+    if (!d.pow2) {
+        for (int s = 0; s < d.npass; ++s) d.rshift[s] = 0;
+    }
+    return true;
+}
+
+template <typename T>
+int make_table(int n, cx<T>** out) {
+    std::vector<cx<T>> h(n);
+    for (int e = 0; e < n; ++e) {
+        const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)e / (long double)n;
+        h[e].x = (T)cosl(ang);
+        h[e].y = (T)sinl(ang);
+    }
+    HIPCHK(hipMalloc((void**)out, sizeof(cx<T>) * (size_t)n));
+    HIPCHK(hipMemcpy(*out, h.data(), sizeof(cx<T>) * (size_t)n, hipMemcpyHostToDevice));
+    return DDN_OK;
+}
+
+std::mutex g_attr_mu;
+std::set<const void*> g_attr_done;
+
+int ensure_lds_attr(const void* fn) {
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    if (g_attr_done.count(fn)) return DDN_OK;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+    g_attr_done.insert(fn);
+    return DDN_OK;
+}
+
+struct EvPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct ddn_plan {
+    int H = 0, W = 0, Wh = 0, Wp = 0, batch = 0, dtype = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    FftDesc fw{}, fh{}, fa{}, fb{};
+    int A = 1, B = 1;          // column transform split H = A x B (A = 1: one pass)
+    int cshift_res2 = 0, cshift_mul = 0, cshift_split = 0;
+    int col_threads = 256;
+    int row_threads = 0;       // 0 = heuristic
+    int tune_cols = 0, tune_A = 0;
+    int num_cu = 256;
+    // device buffers (typed by dtype)
+    void* twW = nullptr;
+    void* twH = nullptr;   // table of length H (outer twiddles and single-pass column transform)
+    void* twA = nullptr;
+    void* twB = nullptr;
+    void* S0 = nullptr;
+    void* S1 = nullptr;
+    void* eK = nullptr;      // [H][Wp] complex, position order
+    void* G = nullptr;       // real resolvent multiplier (includes 1/(HW))
+    void* Gc = nullptr;      // complex resolvent multiplier (injected M)
+    void* eDrow = nullptr;   // injected row-spectral D table (Wh entries) or null
+    void* ed2 = nullptr;     // |eD|^2 table (Wh entries)
+    void* tmp_mult = nullptr;  // scratch multiplier [H][Wp] complex
+    double* partials = nullptr;  // [batch*H][4]
+    int* stop = nullptr;         // [batch]
+    bool have_K = false, have_G = false, injected = false;
+    // timing
+    bool timing = false;
+    std::vector<EvPair> ev_row, ev_col;
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+template <typename T>
+size_t col_lds_bytes(int n, int cshift, int narr) {
+    return (size_t)narr * lds_round(n << cshift) * sizeof(cx<T>) + (size_t)n * sizeof(cx<T>) + 16 * 4 * sizeof(double);
+}
+
+// choose the column tiling; returns false if nothing fits
+template <typename T>
+bool choose_col(ddn_plan* p) {
+    const int H = p->H;
+    const int want = (sizeof(T) == 4) ? 16 : 8;     // columns for a 128-byte run
+    const int minc = (sizeof(T) == 4) ? 8 : 4;      // 64-byte run: still acceptable for one pass
+    auto fit = [&](int n, int narr) {
+        int cs = -1;
+        for (int c = 0; (1 << c) <= 32; ++c) {
+            if (col_lds_bytes<T>(n, c, narr) <= kLdsMax - 1024) cs = c;
+        }
+        return cs;
+    };
+    int A = 1;
+    if (p->tune_A > 0) {
+        A = p->tune_A;
+        if (H % A) return false;
+    } else {
+        int cs = fit(H, 2);
+        if (cs < 0 || (1 << cs) < minc) {
+            // split H = A x B, A the largest factor <= sqrt(H) that keeps both factors transformable
+            A = 1;
+            for (int a = 2; (long)a * a <= (long)H; ++a) {
+                if (H % a == 0) A = a;
+            }
+            if (A == 1) return false;
+        }
+    }
+    p->A = A;
+    p->B = H / A;
+    if (!factorize(p->A, p->fa) || !factorize(p->B, p->fb)) return false;
+    int c2 = fit(p->B, 2), c1 = fit(p->B, 1);
+    if (c2 < 0 || c1 < 0) return false;
+    int lim = 0;
+    while ((1 << lim) < want) ++lim;
+    if (p->tune_cols > 0) {
+        lim = 0;
+        while ((1 << lim) < p->tune_cols) ++lim;
+    }
+    p->cshift_res2 = std::min(c2, lim);
+    p->cshift_mul = std::min(c1, lim);
+    if (A > 1) {
+        const int cA = fit(p->A, 1);
+        if (cA < 0) return false;
+        p->cshift_split = std::min(cA, (sizeof(T) == 4) ? 5 : 4);
+    }
+    return true;
+}
+
+template <typename T>
+int plan_alloc(ddn_plan* p) {
+    const size_t spec = (size_t)p->batch * p->H * p->Wp * sizeof(cx<T>);
+    int rc;
+    if ((rc = make_table<T>(p->W, (cx<T>**)&p->twW))) return rc;
+    if ((rc = make_table<T>(p->H, (cx<T>**)&p->twH))) return rc;
+    if (p->A > 1) {
+        if ((rc = make_table<T>(p->A, (cx<T>**)&p->twA))) return rc;
+        if ((rc = make_table<T>(p->B, (cx<T>**)&p->twB))) return rc;
+    }
+    HIPCHK(hipMalloc(&p->S0, spec));
+    HIPCHK(hipMalloc(&p->S1, spec));
+    HIPCHK(hipMemset(p->S0, 0, spec));
+    HIPCHK(hipMemset(p->S1, 0, spec));
+    const size_t m = (size_t)p->H * p->Wp;
+    HIPCHK(hipMalloc(&p->eK, m * sizeof(cx<T>)));
+    HIPCHK(hipMalloc(&p->G, m * sizeof(T)));
+    HIPCHK(hipMalloc(&p->Gc, m * sizeof(cx<T>)));
+    HIPCHK(hipMalloc(&p->tmp_mult, m * sizeof(cx<T>)));
+    HIPCHK(hipMemset(p->eK, 0, m * sizeof(cx<T>)));
+    HIPCHK(hipMemset(p->G, 0, m * sizeof(T)));
+    HIPCHK(hipMemset(p->Gc, 0, m * sizeof(cx<T>)));
+    HIPCHK(hipMemset(p->tmp_mult, 0, m * sizeof(cx<T>)));
+    HIPCHK(hipMalloc(&p->eDrow, (size_t)p->Wp * sizeof(cx<T>)));
+    HIPCHK(hipMalloc(&p->ed2, (size_t)p->Wp * sizeof(T)));
+    std::vector<T> ed2(p->Wp, (T)0);
+    for (int k = 0; k < p->Wh; ++k) ed2[k] = (T)(2.0L - 2.0L * cosl(2.0L * 3.14159265358979323846264338327950288L * k / p->W));
+    HIPCHK(hipMemcpy(p->ed2, ed2.data(), (size_t)p->Wp * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&p->partials, (size_t)p->batch * p->H * 4 * sizeof(double)));
+    HIPCHK(hipMemset(p->partials, 0, (size_t)p->batch * p->H * 4 * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&p->stop, (size_t)p->batch * sizeof(int)));
+    HIPCHK(hipMemset(p->stop, 0xff, (size_t)p->batch * sizeof(int)));
+    return DDN_OK;
+}
+
+// ------------------------------------------------------------------------------ launch helpers
+struct TimerScope {
+    ddn_plan* p;
+    std::vector<EvPair>* vec;
+    EvPair ev{};
+    bool on;
+    TimerScope(ddn_plan* p_, bool row) : p(p_), vec(row ? &p_->ev_row : &p_->ev_col), on(p_->timing) {
+        if (!on) return;
+        if (p->ev_used == p->ev_pool.size()) {
+            EvPair e;
+            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) {
+                on = false;
+                return;
+            }
+            p->ev_pool.push_back(e);
+        }
+        ev = p->ev_pool[p->ev_used++];
+        (void)hipEventRecord(ev.a, p->stream);
+    }
+    ~TimerScope() {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, p->stream);
+        vec->push_back(ev);
+    }
+};
+
+template <typename T>
+ColMap colmap(const ddn_plan* p) {
+    ColMap m;
+    m.fa = p->fa;
+    m.fb = p->fb;
+    m.A = p->A;
+    m.B = p->B;
+    return m;
+}
+
+inline LossFin no_loss() {
+    LossFin lf;
+    std::memset(&lf, 0, sizeof(lf));
+    return lf;
+}
+
+template <typename T, int MODE>
+int launch_col_one(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t lds) {
+    auto fn = k_col<T, MODE>;
+    int rc = ensure_lds_attr((const void*)fn);
+    if (rc) return rc;
+    TimerScope ts(p, false);
+    hipLaunchKernelGGL(fn, dim3(nblocks), dim3(threads), lds, p->stream, a);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+// One full column stage (forward, pointwise algebra, inverse) in place on S0 (and S1).
+// MODE as in ddn_kernels.hpp; nplanes = images to process.
+template <typename T, int MODE>
+int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const cx<T>* gcplx, int conj_mult, T scale, const LossFin& lf) {
+    constexpr int NARR = (MODE == COL_RES2) ? 2 : 1;
+    ColArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.S0 = (cx<T>*)p->S0;
+    a.S1 = (cx<T>*)p->S1;
+    a.mult = mult;
+    a.greal = greal;
+    a.gcplx = gcplx;
+    a.twH = (const cx<T>*)p->twH;
+    a.H = p->H; a.Wh = p->Wh; a.Wp = p->Wp; a.batch = nplanes;
+    a.conj_mult = conj_mult;
+    a.scale = scale;
+    a.lf = no_loss();
+    if (p->A == 1) {
+        a.fd = p->fb;
+        a.tw = (const cx<T>*)p->twH;
+        a.cshift = (NARR == 2) ? p->cshift_res2 : p->cshift_mul;
+        a.ntile = (p->Wh + (1 << a.cshift) - 1) >> a.cshift;
+        a.nseg = 1; a.row_stride = 1; a.seg_stride = 0;
+        a.outer = 0;
+        a.lf = lf;
+        const size_t lds = col_lds_bytes<T>(a.fd.n, a.cshift, NARR);
+        int threads = std::min(512, std::max(64, ((a.fd.n << a.cshift) / 8 + 63) / 64 * 64));
+        if (p->col_threads > 0) threads = std::min(threads, std::max(p->col_threads, 64));
+        return launch_col_one<T, MODE>(p, a, nplanes * a.ntile, threads, lds);
+    }
+    // split transform: strided length-A stage, middle length-B stage (with the pointwise algebra),
+    // strided length-A inverse stage
+    ColArgs<T> s = a;
+    s.fd = p->fa;
+    s.tw = (const cx<T>*)p->twA;
+    s.cshift = p->cshift_split;
+    s.ntile = (p->Wh + (1 << s.cshift) - 1) >> s.cshift;
+    s.nseg = p->B; s.row_stride = p->B; s.seg_stride = 1;
+    s.outer = 0;
+    s.scale = (T)1;
+    const size_t lds_s = col_lds_bytes<T>(p->A, s.cshift, NARR);
+    const int thr_s = std::min(512, std::max(64, ((p->A << s.cshift) * NARR / 8 + 63) / 64 * 64));
+    int rc;
+    // forward short stage: run as COL_FWD on each array (S0 and, for RES2, S1)
+    s.dir = 0;
+    s.lf = lf;  // the loss of the previous iteration is finalised by the first launch
+    if ((rc = launch_col_one<T, COL_FWD>(p, s, nplanes * s.nseg * s.ntile, thr_s, col_lds_bytes<T>(p->A, s.cshift, 1)))) return rc;
+    s.lf = no_loss();
+    s.lf.stop = lf.stop; s.lf.iter = lf.iter;
+    if (NARR == 2) {
+        std::swap(s.S0, s.S1);
+        if ((rc = launch_col_one<T, COL_FWD>(p, s, nplanes * s.nseg * s.ntile, thr_s, col_lds_bytes<T>(p->A, s.cshift, 1)))) return rc;
+        std::swap(s.S0, s.S1);
+    }
+    (void)lds_s;
+    // middle stage
+    a.fd = p->fb;
+    a.fa = p->fa;
+    a.tw = (const cx<T>*)p->twB;
+    a.cshift = (NARR == 2) ? p->cshift_res2 : p->cshift_mul;
+    a.ntile = (p->Wh + (1 << a.cshift) - 1) >> a.cshift;
+    a.nseg = p->A; a.row_stride = 1; a.seg_stride = p->B;
+    a.outer = (MODE == COL_FWD) ? 1 : 3;
+    a.lf.stop = lf.stop; a.lf.iter = lf.iter;
+    {
+        const size_t lds = col_lds_bytes<T>(a.fd.n, a.cshift, NARR);
+        int threads = std::min(512, std::max(64, ((a.fd.n << a.cshift) / 8 + 63) / 64 * 64));
+        if ((rc = launch_col_one<T, MODE>(p, a, nplanes * a.nseg * a.ntile, threads, lds))) return rc;
+    }
+    if (MODE == COL_FWD) return DDN_OK;
+    // inverse short stage
+    s.dir = 1;
+    if ((rc = launch_col_one<T, COL_FWD>(p, s, nplanes * s.nseg * s.ntile, thr_s, col_lds_bytes<T>(p->A, s.cshift, 1)))) return rc;
+    if (NARR == 2) {
+        std::swap(s.S0, s.S1);
+        if ((rc = launch_col_one<T, COL_FWD>(p, s, nplanes * s.nseg * s.ntile, thr_s, col_lds_bytes<T>(p->A, s.cshift, 1)))) return rc;
+    }
+    return DDN_OK;
+}
+
+struct RowCfg {
+    int V, NG, threads, grid;
+    size_t lds;
+};
+
+template <typename T>
+bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc) {
+    const int W = p->W;
+    if (aligned && W % 4 == 0 && W <= 4096) {
+        rc.V = 4;
+        rc.NG = 4;
+        rc.threads = std::min(256, std::max(64, (W / 16 + 63) / 64 * 64));
+    } else {
+        if (W > 8192) return false;
+        rc.V = 1;
+        rc.NG = 8;
+        rc.threads = std::min(1024, std::max(64, ((W + 7) / 8 + 63) / 64 * 64));
+    }
+    if (p->row_threads > 0 && rc.V == 4) rc.threads = std::min(256, std::max(rc.threads, p->row_threads));
+    rc.lds = row_lds_bytes<T>(W, rc.V);
+    if (rc.lds > kLdsMax) return false;
+    int per_cu = (int)std::min<size_t>(8, kLdsMax / rc.lds);
+    per_cu = std::max(1, std::min(per_cu, 2048 / rc.threads));
+    rc.grid = std::max(1, std::min(work_items, p->num_cu * per_cu));
+    return true;
+}
+
+template <typename T>
+RowCommon<T> row_common(ddn_plan* p, int V, bool consume, bool produce) {
+    RowCommon<T> c;
+    std::memset(&c, 0, sizeof(c));
+    c.H = p->H; c.W = p->W; c.Wp = p->Wp; c.batch = p->batch;
+    c.V_groups = p->W / V;
+    c.fw = p->fw;
+    c.twW = (const cx<T>*)p->twW;
+    c.S0 = (cx<T>*)p->S0;
+    c.S1 = (cx<T>*)p->S1;
+    c.eDrow = p->injected ? (const cx<T>*)p->eDrow : nullptr;
+    c.stop = p->stop;
+    c.partials = p->partials;
+    c.do_consume = consume ? 1 : 0;
+    c.do_produce = produce ? 1 : 0;
+    return c;
+}
+
+inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
+
+#define LAUNCH_ROW(KERN, ARGS, CFG)                                                                          \
+    do {                                                                                                     \
+        int rc_;                                                                                             \
+        TimerScope ts_(p, true);                                                                             \
+        if ((CFG).V == 4) {                                                                                  \
+            auto fn_ = KERN<T, 4, 4, 256>;                                                                   \
+            if ((rc_ = ensure_lds_attr((const void*)fn_))) return rc_;                                       \
+            hipLaunchKernelGGL(fn_, dim3((CFG).grid), dim3((CFG).threads), (CFG).lds, p->stream, ARGS);      \
+        } else {                                                                                             \
+            auto fn_ = KERN<T, 1, 8, 1024>;                                                                  \
+            if ((rc_ = ensure_lds_attr((const void*)fn_))) return rc_;                                       \
+            hipLaunchKernelGGL(fn_, dim3((CFG).grid), dim3((CFG).threads), (CFG).lds, p->stream, ARGS);      \
+        }                                                                                                    \
+        HIPCHK(hipGetLastError());                                                                           \
+    } while (0)
+
+template <typename T>
+int launch_finalize(ddn_plan* p, const LossFin& lf) {
+    hipLaunchKernelGGL(k_loss_finalize, dim3(p->batch), dim3(256), 0, p->stream, lf);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+LossFin make_lf(ddn_plan* p, double* ring, int iter, int tol_kind, double tol, int first_iter, bool use_stop) {
+    LossFin lf;
+    std::memset(&lf, 0, sizeof(lf));
+    lf.partials = p->partials;
+    lf.ring = (ring && iter >= 1) ? ring + (size_t)(iter - 1) * p->batch * 8 : nullptr;
+    lf.stop = use_stop ? p->stop : nullptr;
+    lf.rows_per_plane = p->H;
+    lf.tol_kind = tol_kind;
+    lf.iter = iter;
+    lf.first_iter = first_iter;
+    lf.tol = tol;
+    lf.npix = (double)p->H * (double)p->W;
+    lf.enabled = (iter >= 1 && (ring != nullptr || tol_kind > 0)) ? 1 : 0;
+    return lf;
+}
+
+template <typename T>
+int reset_stop(ddn_plan* p) {
+    HIPCHK(hipMemsetAsync(p->stop, 0xff, (size_t)p->batch * sizeof(int), p->stream));
+    return DDN_OK;
+}
+
+template <typename T>
+int finish_iters(ddn_plan* p, int* iters_done_dev, int n_iters) {
+    if (!iters_done_dev) return DDN_OK;
+    hipLaunchKernelGGL(k_iters_done, dim3((p->batch + 255) / 256), dim3(256), 0, p->stream, p->stop, iters_done_dev, p->batch, n_iters);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+// ------------------------------------------------------------------------- plain transforms
+template <typename T>
+int rows_r2c(ddn_plan* p, const T* src, int nplanes) {
+    PlainRowArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.H = p->H; a.W = p->W; a.Wp = p->Wp; a.batch = nplanes;
+    a.fw = p->fw; a.twW = (const cx<T>*)p->twW; a.S = (cx<T>*)p->S0; a.src = src;
+    const size_t lds = row_lds_bytes<T>(p->W, 1);
+    if (lds > kLdsMax) return fail(DDN_E_UNSUPPORTED, "row length too large for LDS");
+    auto fn = k_rows_r2c<T>;
+    int rc;
+    if ((rc = ensure_lds_attr((const void*)fn))) return rc;
+    const int threads = std::min(1024, std::max(64, (p->W / 8 + 63) / 64 * 64));
+    const int pairs = nplanes * ((p->H + 1) / 2);
+    hipLaunchKernelGGL(fn, dim3(std::min(pairs, p->num_cu * 4)), dim3(threads), lds, p->stream, a);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+template <typename T>
+int rows_c2r(ddn_plan* p, T* dst, int nplanes, T scale, const T* add) {
+    PlainRowArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.H = p->H; a.W = p->W; a.Wp = p->Wp; a.batch = nplanes;
+    a.fw = p->fw; a.twW = (const cx<T>*)p->twW; a.S = (cx<T>*)p->S0; a.dst = dst; a.scale = scale; a.add = add;
+    const size_t lds = row_lds_bytes<T>(p->W, 1);
+    auto fn = k_rows_c2r<T>;
+    int rc;
+    if ((rc = ensure_lds_attr((const void*)fn))) return rc;
+    const int threads = std::min(1024, std::max(64, (p->W / 8 + 63) / 64 * 64));
+    const int pairs = nplanes * ((p->H + 1) / 2);
+    hipLaunchKernelGGL(fn, dim3(std::min(pairs, p->num_cu * 4)), dim3(threads), lds, p->stream, a);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
+
+// y = real(ifft2(m * fft2(x))) with a position-ordered half-plane multiplier
+template <typename T>
+int apply_mult(ddn_plan* p, const cx<T>* mult, int conj_mult, const T* x, T* y, int nplanes) {
+    int rc;
+    if ((rc = rows_r2c<T>(p, x, nplanes))) return rc;
+    const T scale = (T)(1.0 / ((double)p->H * (double)p->W));
+    if ((rc = col_stage<T, COL_MUL>(p, nplanes, mult, nullptr, nullptr, conj_mult, scale, no_loss()))) return rc;
+    return rows_c2r<T>(p, y, nplanes, (T)1, nullptr);
+}
+
+template <typename T>
+int import_full(ddn_plan* p, const void* full, int cdtype, int recip, int conj_in, double scale, cx<T>* out, T* out_real) {
+    const size_t total = (size_t)p->H * p->Wh;
+    if (cdtype == DDN_C64)
+        hipLaunchKernelGGL((k_import_mult<T, float>), dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<float>*)full, out, out_real,
+                           p->H, p->W, p->Wh, p->Wp, colmap<T>(p), recip, conj_in, scale);
+    else
+        hipLaunchKernelGGL((k_import_mult<T, double>), dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<double>*)full, out, out_real,
+                           p->H, p->W, p->Wh, p->Wp, colmap<T>(p), recip, conj_in, scale);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+// --------------------------------------------------------------------------------- set-up
+template <typename T>
+int set_kernel_impl(ddn_plan* p, const double* taps, int kh, int kw, bool as_convolution, cx<T>* out) {
+    // impulse response image: correlation centred at (kh/2, kw/2) (eig:41-56), or the circular
+    // convolution kernel of circular_convolve2d: zero-padded taps rolled by (-kh)//2 (conv:38-40)
+    const int H = p->H, W = p->W;
+    std::vector<T> img((size_t)H * W, (T)0);
+    for (int u = 0; u < kh; ++u)
+        for (int v = 0; v < kw; ++v) {
+            const T tap = (T)(float)taps[u * kw + v];
+            long r, c;
+            if (as_convolution) {
+                const long sh = -((kh + 1) / 2), sw = -((kw + 1) / 2);  // python floor division of -k by 2
+                r = ((u + sh) % H + H) % H;
+                c = ((v + sw) % W + W) % W;
+                if (u >= H || v >= W) continue;  // the reference writes padded[:kh,:kw]; taps beyond the image would raise
+            } else {
+                r = (((long)kh / 2 - u) % H + H) % H;
+                c = (((long)kw / 2 - v) % W + W) % W;
+            }
+            img[(size_t)r * W + c] += tap;
+        }
+    T* dimg = nullptr;
+    HIPCHK(hipMalloc((void**)&dimg, sizeof(T) * (size_t)H * W));
+    HIPCHK(hipMemcpyAsync(dimg, img.data(), sizeof(T) * (size_t)H * W, hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    int rc = rows_r2c<T>(p, dimg, 1);
+    if (!rc) rc = col_stage<T, COL_FWD>(p, 1, nullptr, nullptr, nullptr, 0, (T)1, no_loss());
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(out, p->S0, sizeof(cx<T>) * (size_t)H * p->Wp, hipMemcpyDeviceToDevice, p->stream);
+        if (e != hipSuccess) rc = fail(DDN_E_HIP, hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(dimg);
+    return rc;
+}
+
+template <typename T>
+int set_resolvent_impl(ddn_plan* p, double cK, double cD, const void* M_dev, int cdtype) {
+    const double scale = 1.0 / ((double)p->H * (double)p->W);
+    if (M_dev) {
+        int rc = import_full<T>(p, M_dev, cdtype, 1, 0, scale, (cx<T>*)p->Gc, (T*)p->G);
+        if (rc) return rc;
+        p->have_G = true;
+        return DDN_OK;
+    }
+    if (!p->have_K) return fail(DDN_E_STATE, "set_resolvent: no blur kernel set");
+    const size_t total = (size_t)p->H * p->Wh;
+    hipLaunchKernelGGL(k_make_G<T>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<T>*)p->eK, (const T*)p->ed2, (T*)p->G,
+                       p->H, p->Wh, p->Wp, (T)cK, (T)cD, (T)scale);
+    HIPCHK(hipGetLastError());
+    p->have_G = true;
+    return DDN_OK;
+}
+
+// ----------------------------------------------------------------------------- solver loops
+template <typename T>
+int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, double rho, double gamma, int objective, int n_iters,
+                 int tol_kind, double tol, int first_loss_iter, double* ring, int* iters_done) {
+    if (!p->have_K || !p->have_G) return fail(DDN_E_STATE, "pdr_run: operators not set");
+    const size_t plane = (size_t)p->batch * p->H * p->W;
+    RowCfg cfg;
+    const bool al = aligned16(z1) && aligned16(z2) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
+    if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    PdrArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.z1 = (T*)z1; a.z20 = (T*)z2; a.z21 = (T*)z2 + plane; a.z22 = (T*)z2 + 2 * plane; a.b = (const T*)b;
+    a.t = (T)t; a.rho = (T)rho; a.tg = (T)(t * gamma); a.l2div = (T)(2 * t + 1); a.objective = objective;
+    int rc;
+    if ((rc = reset_stop<T>(p))) return rc;
+    const cx<T>* gc = p->injected ? (const cx<T>*)p->Gc : nullptr;
+    if (n_iters > 0) {
+        a.c = row_common<T>(p, cfg.V, false, true);
+        LAUNCH_ROW(k_pdr_row, a, cfg);
+        for (int c = 1; c <= n_iters; ++c) {
+            LossFin lf = make_lf(p, ring, c - 1, tol_kind, tol, first_loss_iter, true);
+            if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
+            a.c = row_common<T>(p, cfg.V, true, c < n_iters);
+            LAUNCH_ROW(k_pdr_row, a, cfg);
+        }
+        if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, tol_kind, tol, first_loss_iter, true)))) return rc;
+    }
+    return finish_iters<T>(p, iters_done, n_iters);
+}
+
+template <typename T>
+int pddr_run_impl(ddn_plan* p, void* pp, void* q, const void* b, double t, double rho, double gamma, int n_iters,
+                  int tol_kind, double tol, int first_loss_iter, double* ring, int* iters_done) {
+    if (!p->have_K || !p->have_G) return fail(DDN_E_STATE, "pddr_run: operators not set");
+    const size_t plane = (size_t)p->batch * p->H * p->W;
+    RowCfg cfg;
+    const bool al = aligned16(pp) && aligned16(q) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
+    if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    PddrArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.p = (T*)pp; a.q0 = (T*)q; a.q1 = (T*)q + plane; a.q2 = (T*)q + 2 * plane; a.b = (const T*)b;
+    a.t = (T)t; a.it = (T)(1.0 / t); a.rho = (T)rho; a.itg = (T)((1.0 / t) * gamma);
+    int rc;
+    if ((rc = reset_stop<T>(p))) return rc;
+    const cx<T>* gc = p->injected ? (const cx<T>*)p->Gc : nullptr;
+    if (n_iters > 0) {
+        a.c = row_common<T>(p, cfg.V, false, true);
+        LAUNCH_ROW(k_pddr_row, a, cfg);
+        for (int c = 1; c <= n_iters; ++c) {
+            LossFin lf = make_lf(p, ring, c - 1, tol_kind, tol, first_loss_iter, true);
+            if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
+            a.c = row_common<T>(p, cfg.V, true, c < n_iters);
+            LAUNCH_ROW(k_pddr_row, a, cfg);
+        }
+        if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, tol_kind, tol, first_loss_iter, true)))) return rc;
+    }
+    return finish_iters<T>(p, iters_done, n_iters);
+}
+
+template <typename T>
+int admm_run_impl(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b, double t, double rho, double gamma, int objective,
+                  int n_iters, int tol_kind, double tol, int first_loss_iter, double* ring, int* iters_done, void* sol) {
+    if (!p->have_K || !p->have_G) return fail(DDN_E_STATE, "admm_run: operators not set");
+    if (!sol) return fail(DDN_E_ARG, "admm_run: sol_out_dev is null");
+    const size_t plane = (size_t)p->batch * p->H * p->W;
+    RowCfg cfg;
+    const bool al = aligned16(u) && aligned16(w) && aligned16(y) && aligned16(z) && aligned16(b) && aligned16(sol) && ((plane * sizeof(T)) % 16 == 0);
+    if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    AdmmArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.u = (T*)u; a.w = (T*)w;
+    a.y0 = (T*)y; a.y1 = (T*)y + plane; a.y2 = (T*)y + 2 * plane;
+    a.z0 = (T*)z; a.z1 = (T*)z + plane; a.z2 = (T*)z + 2 * plane;
+    a.b = (const T*)b;
+    a.t = (T)t; a.it = (T)(1.0 / t); a.rho = (T)rho; a.omr = (T)(1.0 - rho); a.itg = (T)((1.0 / t) * gamma);
+    a.l2div = (T)(2 * (1.0 / t) + 1); a.objective = objective;
+    int rc;
+    if ((rc = reset_stop<T>(p))) return rc;
+    const cx<T>* gc = p->injected ? (const cx<T>*)p->Gc : nullptr;
+    // produce the transform inputs of the first solve
+    a.c = row_common<T>(p, cfg.V, false, true);
+    a.sol = nullptr; a.sol_only = 0;
+    LAUNCH_ROW(k_admm_row, a, cfg);
+    for (int c = 1; c <= n_iters; ++c) {
+        // partial sums written by call c-1 describe sol of iteration c-2
+        LossFin lf = make_lf(p, ring, c - 2, tol_kind, tol, first_loss_iter, true);
+        if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
+        a.c = row_common<T>(p, cfg.V, true, true);
+        a.sol = (tol_kind > 0) ? (T*)sol : nullptr;
+        LAUNCH_ROW(k_admm_row, a, cfg);
+    }
+    {
+        LossFin lf = make_lf(p, ring, n_iters - 1, tol_kind, tol, first_loss_iter, true);
+        if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
+        a.c = row_common<T>(p, cfg.V, true, false);
+        a.sol = (T*)sol; a.sol_only = 1;
+        LAUNCH_ROW(k_admm_row, a, cfg);
+        if (n_iters >= 1)
+            if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, tol_kind, tol, first_loss_iter, true)))) return rc;
+    }
+    return finish_iters<T>(p, iters_done, n_iters);
+}
+
+template <typename T>
+int cp_run_impl(ddn_plan* p, void* x, void* z, void* y, const void* b, double t, double s, double gamma, int objective, int n_iters, double* ring) {
+    if (!p->have_K) return fail(DDN_E_STATE, "cp_run: operators not set");
+    const size_t plane = (size_t)p->batch * p->H * p->W;
+    RowCfg cfg;
+    const bool al = aligned16(x) && aligned16(z) && aligned16(y) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
+    if (!row_cfg<T>(p, al, p->batch * ((p->H + 1) / 2), cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    CpArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = (T*)x; a.z = (T*)z; a.y0 = (T*)y; a.y1 = (T*)y + plane; a.y2 = (T*)y + 2 * plane; a.b = (const T*)b;
+    a.t = (T)t; a.s = (T)s; a.is = (T)(1.0 / s); a.isg = (T)((1.0 / s) * gamma); a.l2div = (T)(2 * (1.0 / s) + 1); a.objective = objective;
+    int rc;
+    if ((rc = reset_stop<T>(p))) return rc;
+    const T scale = (T)(1.0 / ((double)p->H * (double)p->W));
+    if (n_iters > 0) {
+        a.step = 1;
+        a.c = row_common<T>(p, cfg.V, false, true);
+        a.c.stop = nullptr;
+        LAUNCH_ROW(k_cp_row, a, cfg);
+        for (int c = 1; c <= n_iters; ++c) {
+            LossFin lf = make_lf(p, ring, c - 1, 0, 0.0, 1, false);
+            if ((rc = col_stage<T, COL_MUL>(p, p->batch, (const cx<T>*)p->eK, nullptr, nullptr, 0, scale, lf))) return rc;
+            a.step = 0;
+            a.c = row_common<T>(p, cfg.V, true, true);
+            a.c.stop = nullptr;
+            LAUNCH_ROW(k_cp_row, a, cfg);
+            if ((rc = col_stage<T, COL_MUL>(p, p->batch, (const cx<T>*)p->eK, nullptr, nullptr, 1, scale, no_loss()))) return rc;
+            a.step = 1;
+            a.c = row_common<T>(p, cfg.V, true, c < n_iters);
+            a.c.stop = nullptr;
+            LAUNCH_ROW(k_cp_row, a, cfg);
+        }
+        if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, 0, 0.0, 1, false)))) return rc;
+    }
+    return DDN_OK;
+}
+
+template <typename T>
+int apply_impl(ddn_plan* p, int op, const void* x, void* y) {
+    const size_t n = (size_t)p->batch * p->H * p->W;
+    const size_t total = (size_t)p->H * p->Wh;
+    switch (op) {
+        case DDN_OP_K:
+        case DDN_OP_KT:
+            if (!p->have_K) return fail(DDN_E_STATE, "apply: no blur kernel set");
+            return apply_mult<T>(p, (const cx<T>*)p->eK, op == DDN_OP_KT, (const T*)x, (T*)y, p->batch);
+        case DDN_OP_D:
+        case DDN_OP_DT:
+            if (p->injected) {
+                hipLaunchKernelGGL(k_bcast_row<T>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<T>*)p->eDrow, (cx<T>*)p->tmp_mult, p->H, p->Wh, p->Wp);
+                HIPCHK(hipGetLastError());
+                return apply_mult<T>(p, (const cx<T>*)p->tmp_mult, op == DDN_OP_DT, (const T*)x, (T*)y, p->batch);
+            }
+            if (x == y) return fail(DDN_E_ARG, "apply D/DT: in-place not supported");
+            hipLaunchKernelGGL(k_stencil<T>, dim3(ew_grid(n)), dim3(256), 0, p->stream, (const T*)x, (T*)y, p->W, n, op == DDN_OP_DT ? 1 : 0);
+            HIPCHK(hipGetLastError());
+            return DDN_OK;
+        case DDN_OP_RESOLVENT: {
+            if (!p->have_G) return fail(DDN_E_STATE, "apply: resolvent not set");
+            int rc;
+            if ((rc = rows_r2c<T>(p, (const T*)x, p->batch))) return rc;
+            if ((rc = col_stage<T, COL_MULR>(p, p->batch, nullptr, (const T*)p->G, p->injected ? (const cx<T>*)p->Gc : nullptr, 0, (T)1, no_loss()))) return rc;
+            return rows_c2r<T>(p, (T*)y, p->batch, (T)1, nullptr);
+        }
+        case DDN_OP_MAT: {
+            if (!p->have_K) return fail(DDN_E_STATE, "apply: no blur kernel set");
+            hipLaunchKernelGGL(k_make_mat<T>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<T>*)p->eK, (const T*)p->ed2, (cx<T>*)p->tmp_mult, p->H, p->Wh, p->Wp);
+            HIPCHK(hipGetLastError());
+            return apply_mult<T>(p, (const cx<T>*)p->tmp_mult, 0, (const T*)x, (T*)y, p->batch);
+        }
+    }
+    return fail(DDN_E_ARG, "apply: unknown operator");
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int ddn_version(void) { return 100; }
+const char* ddn_last_error(void) { return g_err.c_str(); }
+
+int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* stream) {
+    if (!out || H < 1 || W < 2 || batch < 1 || (dtype != DDN_F32 && dtype != DDN_F64)) return fail(DDN_E_ARG, "plan_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DDN_E_HIP, "plan_create: no HIP device");
+    ddn_plan* p = new ddn_plan();
+    p->H = H; p->W = W; p->batch = batch; p->dtype = dtype; p->stream = (hipStream_t)stream;
+    p->Wh = W / 2 + 1;
+    p->Wp = (p->Wh + 31) / 32 * 32;
+    (void)hipGetDevice(&p->device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->num_cu = prop.multiProcessorCount;
+    if (!factorize(W, p->fw) || !factorize(H, p->fh)) {
+        delete p;
+        return fail(DDN_E_UNSUPPORTED, "plan_create: image size has a prime factor > 13");
+    }
+    const bool ok = dtype == DDN_F32 ? choose_col<float>(p) : choose_col<double>(p);
+    if (!ok) {
+        delete p;
+        return fail(DDN_E_UNSUPPORTED, "plan_create: column transform does not fit LDS");
+    }
+    if (p->A == 1) p->fb = p->fh;
+    const size_t rl = dtype == DDN_F32 ? row_lds_bytes<float>(W, 1) : row_lds_bytes<double>(W, 1);
+    if (rl > kLdsMax) {
+        delete p;
+        return fail(DDN_E_UNSUPPORTED, "plan_create: row length too large for LDS");
+    }
+    int rc = dtype == DDN_F32 ? plan_alloc<float>(p) : plan_alloc<double>(p);
+    if (rc) {
+        ddn_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return DDN_OK;
+}
+
+int ddn_plan_destroy(ddn_plan* p) {
+    if (!p) return DDN_OK;
+    void* bufs[] = {p->twW, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    for (auto& e : p->ev_pool) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    delete p;
+    return DDN_OK;
+}
+
+int ddn_plan_set_stream(ddn_plan* p, void* stream) {
+    if (!p) return fail(DDN_E_ARG, "null plan");
+    p->stream = (hipStream_t)stream;
+    return DDN_OK;
+}
+
+int ddn_plan_tune(ddn_plan* p, int cols_per_block, int split_A, int row_threads) {
+    if (!p) return fail(DDN_E_ARG, "null plan");
+    if (p->have_K) return fail(DDN_E_STATE, "plan_tune must precede set_kernel / set_eig");
+    if (split_A > 0 && p->H % split_A) return fail(DDN_E_ARG, "plan_tune: split_A does not divide H");
+    const int oldA = p->A;
+    p->tune_cols = cols_per_block;
+    p->tune_A = split_A;
+    p->row_threads = row_threads;
+    const bool ok = p->dtype == DDN_F32 ? choose_col<float>(p) : choose_col<double>(p);
+    if (!ok) return fail(DDN_E_UNSUPPORTED, "plan_tune: tiling does not fit LDS");
+    if (p->A == 1) p->fb = p->fh;
+    if (p->A != oldA && p->A > 1) {
+        if (p->twA) (void)hipFree(p->twA);
+        if (p->twB) (void)hipFree(p->twB);
+        p->twA = p->twB = nullptr;
+        int rc;
+        if (p->dtype == DDN_F32) {
+            if ((rc = make_table<float>(p->A, (cx<float>**)&p->twA))) return rc;
+            if ((rc = make_table<float>(p->B, (cx<float>**)&p->twB))) return rc;
+        } else {
+            if ((rc = make_table<double>(p->A, (cx<double>**)&p->twA))) return rc;
+            if ((rc = make_table<double>(p->B, (cx<double>**)&p->twB))) return rc;
+        }
+    }
+    return DDN_OK;
+}
+
+int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
+    if (!p || !taps || kh < 1 || kw < 1) return fail(DDN_E_ARG, "set_kernel: bad arguments");
+    int rc = p->dtype == DDN_F32 ? set_kernel_impl<float>(p, taps, kh, kw, false, (cx<float>*)p->eK)
+                                 : set_kernel_impl<double>(p, taps, kh, kw, false, (cx<double>*)p->eK);
+    if (rc) return rc;
+    p->have_K = true;
+    p->injected = false;
+    return DDN_OK;
+}
+
+int ddn_plan_set_eig(ddn_plan* p, const void* eigK, const void* eigD, int cdtype) {
+    if (!p || !eigK) return fail(DDN_E_ARG, "set_eig: bad arguments");
+    int rc;
+    if (p->dtype == DDN_F32) rc = import_full<float>(p, eigK, cdtype, 0, 0, 1.0, (cx<float>*)p->eK, nullptr);
+    else rc = import_full<double>(p, eigK, cdtype, 0, 0, 1.0, (cx<double>*)p->eK, nullptr);
+    if (rc) return rc;
+    p->have_K = true;
+    // row-spectral D table: Hermitian-symmetrised first row of eigD, or the analytic 1 - w^k
+    const int W = p->W, Wh = p->Wh;
+    std::vector<double> row(2 * (size_t)W);
+    if (eigD) {
+        if (cdtype == DDN_C64) {
+            std::vector<float> t(2 * (size_t)W);
+            HIPCHK(hipMemcpy(t.data(), eigD, sizeof(float) * 2 * W, hipMemcpyDeviceToHost));
+            for (int i = 0; i < 2 * W; ++i) row[i] = t[i];
+        } else {
+            HIPCHK(hipMemcpy(row.data(), eigD, sizeof(double) * 2 * W, hipMemcpyDeviceToHost));
+        }
+    } else {
+        for (int k = 0; k < W; ++k) {
+            const long double ang = -2.0L * 3.14159265358979323846264338327950288L * k / W;
+            row[2 * k] = (double)(1.0L - cosl(ang));
+            row[2 * k + 1] = (double)(-sinl(ang));
+        }
+    }
+    std::vector<double> sym(2 * (size_t)p->Wp, 0.0), ed2(p->Wp, 0.0);
+    for (int k = 0; k < Wh; ++k) {
+        const int km = k == 0 ? 0 : W - k;
+        sym[2 * k] = 0.5 * (row[2 * k] + row[2 * km]);
+        sym[2 * k + 1] = 0.5 * (row[2 * k + 1] - row[2 * km + 1]);
+    }
+    if (p->dtype == DDN_F32) {
+        std::vector<float> f(sym.begin(), sym.end());
+        HIPCHK(hipMemcpy(p->eDrow, f.data(), sizeof(float) * 2 * p->Wp, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMemcpy(p->eDrow, sym.data(), sizeof(double) * 2 * p->Wp, hipMemcpyHostToDevice));
+    }
+    p->injected = true;
+    return DDN_OK;
+}
+
+int ddn_plan_set_resolvent(ddn_plan* p, double cK, double cD, const void* M_dev, int cdtype) {
+    if (!p) return fail(DDN_E_ARG, "null plan");
+    if (p->injected && !M_dev) return fail(DDN_E_ARG, "set_resolvent: injected eigen arrays need the injected eig_vals_mat too");
+    return p->dtype == DDN_F32 ? set_resolvent_impl<float>(p, cK, cD, M_dev, cdtype) : set_resolvent_impl<double>(p, cK, cD, M_dev, cdtype);
+}
+
+int ddn_plan_get_eigK(ddn_plan* p, void* out_dev) {
+    if (!p || !out_dev) return fail(DDN_E_ARG, "get_eigK: bad arguments");
+    if (!p->have_K) return fail(DDN_E_STATE, "get_eigK: no blur kernel set");
+    const size_t total = (size_t)p->H * p->W;
+    if (p->dtype == DDN_F32)
+        hipLaunchKernelGGL(k_export_full<float>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<float>*)p->eK, (cx<float>*)out_dev, p->H, p->W, p->Wp, colmap<float>(p));
+    else
+        hipLaunchKernelGGL(k_export_full<double>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<double>*)p->eK, (cx<double>*)out_dev, p->H, p->W, p->Wp, colmap<double>(p));
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+int ddn_apply(ddn_plan* p, int op, const void* x, void* y) {
+    if (!p || !x || !y) return fail(DDN_E_ARG, "apply: bad arguments");
+    return p->dtype == DDN_F32 ? apply_impl<float>(p, op, x, y) : apply_impl<double>(p, op, x, y);
+}
+
+int ddn_apply_multiplier(ddn_plan* p, const void* mult, int cdtype, int flags, const void* x, void* y) {
+    if (!p || !mult || !x || !y) return fail(DDN_E_ARG, "apply_multiplier: bad arguments");
+    int rc;
+    if (p->dtype == DDN_F32) {
+        if ((rc = import_full<float>(p, mult, cdtype, (flags >> 1) & 1, flags & 1, 1.0, (cx<float>*)p->tmp_mult, nullptr))) return rc;
+        return apply_mult<float>(p, (const cx<float>*)p->tmp_mult, 0, (const float*)x, (float*)y, p->batch);
+    }
+    if ((rc = import_full<double>(p, mult, cdtype, (flags >> 1) & 1, flags & 1, 1.0, (cx<double>*)p->tmp_mult, nullptr))) return rc;
+    return apply_mult<double>(p, (const cx<double>*)p->tmp_mult, 0, (const double*)x, (double*)y, p->batch);
+}
+
+int ddn_circular_convolve2d(ddn_plan* p, const double* taps, int kh, int kw, const void* image, void* out) {
+    if (!p || !taps || !image || !out) return fail(DDN_E_ARG, "circular_convolve2d: bad arguments");
+    if (kh > p->H || kw > p->W) return fail(DDN_E_ARG, "circular_convolve2d: kernel larger than the image");
+    int rc;
+    if (p->dtype == DDN_F32) {
+        if ((rc = set_kernel_impl<float>(p, taps, kh, kw, true, (cx<float>*)p->tmp_mult))) return rc;
+        return apply_mult<float>(p, (const cx<float>*)p->tmp_mult, 0, (const float*)image, (float*)out, p->batch);
+    }
+    if ((rc = set_kernel_impl<double>(p, taps, kh, kw, true, (cx<double>*)p->tmp_mult))) return rc;
+    return apply_mult<double>(p, (const cx<double>*)p->tmp_mult, 0, (const double*)image, (double*)out, p->batch);
+}
+
+int ddn_prox(int kind, int dtype, const void* x, void* y, size_t n, double lambda, void* stream) {
+    if (!x || !y || kind < 0 || kind > 4) return fail(DDN_E_ARG, "prox: bad arguments");
+    if (n == 0) return DDN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    double* norm2 = nullptr;
+    if (kind == DDN_PROX_L2) {
+        // whole-tensor norm first (prox:14)
+        double* part = nullptr;
+        const int chunks = 256;
+        HIPCHK(hipMalloc((void**)&part, sizeof(double) * (2 * chunks + 4)));
+        if (dtype == DDN_F32) hipLaunchKernelGGL(k_reduce_partial<float>, dim3(chunks), dim3(256), 0, st, (const float*)x, (const float*)nullptr, n, chunks, part);
+        else hipLaunchKernelGGL(k_reduce_partial<double>, dim3(chunks), dim3(256), 0, st, (const double*)x, (const double*)nullptr, n, chunks, part);
+        hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(64), 0, st, part, chunks, 1.0, part + 2 * chunks);
+        norm2 = part + 2 * chunks + 2;  // mean d^2 with npix = 1 -> sum of squares
+        if (dtype == DDN_F32) hipLaunchKernelGGL(k_prox<float>, dim3(ew_grid(n)), dim3(256), 0, st, kind, (const float*)x, (float*)y, n, (float)lambda, norm2);
+        else hipLaunchKernelGGL(k_prox<double>, dim3(ew_grid(n)), dim3(256), 0, st, kind, (const double*)x, (double*)y, n, lambda, norm2);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        (void)hipFree(part);
+        return DDN_OK;
+    }
+    if (dtype == DDN_F32) hipLaunchKernelGGL(k_prox<float>, dim3(ew_grid(n)), dim3(256), 0, st, kind, (const float*)x, (float*)y, n, (float)lambda, norm2);
+    else hipLaunchKernelGGL(k_prox<double>, dim3(ew_grid(n)), dim3(256), 0, st, kind, (const double*)x, (double*)y, n, lambda, norm2);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+int ddn_reduce(int dtype, const void* x, const void* y, size_t n_per_image, int batch, double* out4, void* stream) {
+    if (!x || !out4 || batch < 1) return fail(DDN_E_ARG, "reduce: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = (int)std::min<size_t>(256, std::max<size_t>(1, n_per_image / 4096));
+    double* part = nullptr;
+    HIPCHK(hipMalloc((void**)&part, sizeof(double) * 2 * (size_t)chunks * batch));
+    if (dtype == DDN_F32) hipLaunchKernelGGL(k_reduce_partial<float>, dim3(chunks * batch), dim3(256), 0, st, (const float*)x, (const float*)y, n_per_image, chunks, part);
+    else hipLaunchKernelGGL(k_reduce_partial<double>, dim3(chunks * batch), dim3(256), 0, st, (const double*)x, (const double*)y, n_per_image, chunks, part);
+    hipLaunchKernelGGL(k_reduce_final, dim3(batch), dim3(64), 0, st, part, chunks, (double)n_per_image, out4);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(part);
+    return DDN_OK;
+}
+
+int ddn_cp_run(ddn_plan* p, void* x, void* z, void* y, const void* b, double t, double s, double gamma, int objective, int n_iters, double* ring) {
+    if (!p || !x || !z || !y || !b || n_iters < 0) return fail(DDN_E_ARG, "cp_run: bad arguments");
+    if (objective != DDN_OBJ_L1 && objective != DDN_OBJ_L2) return fail(DDN_E_ARG, "Invalid objective function. Choose 'l1' or 'l2'.");
+    p->ev_row.clear(); p->ev_col.clear(); p->ev_used = 0;
+    return p->dtype == DDN_F32 ? cp_run_impl<float>(p, x, z, y, b, t, s, gamma, objective, n_iters, ring)
+                               : cp_run_impl<double>(p, x, z, y, b, t, s, gamma, objective, n_iters, ring);
+}
+
+int ddn_admm_run(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b, double t, double rho, double gamma, int objective, int n_iters,
+                 int tol_kind, double tol, int first_loss_iter, double* ring, int* iters_done, void* sol) {
+    if (!p || !u || !w || !y || !z || !b || n_iters < 0) return fail(DDN_E_ARG, "admm_run: bad arguments");
+    if (objective != DDN_OBJ_L1 && objective != DDN_OBJ_L2) return fail(DDN_E_ARG, "Invalid objective function. Choose 'l1' or 'l2'.");
+    p->ev_row.clear(); p->ev_col.clear(); p->ev_used = 0;
+    return p->dtype == DDN_F32 ? admm_run_impl<float>(p, u, w, y, z, b, t, rho, gamma, objective, n_iters, tol_kind, tol, first_loss_iter, ring, iters_done, sol)
+                               : admm_run_impl<double>(p, u, w, y, z, b, t, rho, gamma, objective, n_iters, tol_kind, tol, first_loss_iter, ring, iters_done, sol);
+}
+
+int ddn_pdr_run(ddn_plan* p, void* z1, void* z2, const void* b, double t, double rho, double gamma, int objective, int n_iters,
+                int tol_kind, double tol, int first_loss_iter, double* ring, int* iters_done) {
+    if (!p || !z1 || !z2 || !b || n_iters < 0) return fail(DDN_E_ARG, "pdr_run: bad arguments");
+    p->ev_row.clear(); p->ev_col.clear(); p->ev_used = 0;
+    return p->dtype == DDN_F32 ? pdr_run_impl<float>(p, z1, z2, b, t, rho, gamma, objective, n_iters, tol_kind, tol, first_loss_iter, ring, iters_done)
+                               : pdr_run_impl<double>(p, z1, z2, b, t, rho, gamma, objective, n_iters, tol_kind, tol, first_loss_iter, ring, iters_done);
+}
+
+int ddn_pddr_run(ddn_plan* p, void* pp, void* q, const void* b, double t, double rho, double gamma, int n_iters,
+                 int tol_kind, double tol, int first_loss_iter, double* ring, int* iters_done) {
+    if (!p || !pp || !q || !b || n_iters < 0) return fail(DDN_E_ARG, "pddr_run: bad arguments");
+    p->ev_row.clear(); p->ev_col.clear(); p->ev_used = 0;
+    return p->dtype == DDN_F32 ? pddr_run_impl<float>(p, pp, q, b, t, rho, gamma, n_iters, tol_kind, tol, first_loss_iter, ring, iters_done)
+                               : pddr_run_impl<double>(p, pp, q, b, t, rho, gamma, n_iters, tol_kind, tol, first_loss_iter, ring, iters_done);
+}
+
+int ddn_plan_enable_timing(ddn_plan* p, int on) {
+    if (!p) return fail(DDN_E_ARG, "null plan");
+    p->timing = on != 0;
+    return DDN_OK;
+}
+
+int ddn_plan_last_timing(ddn_plan* p, double* row_ms, double* col_ms, int* n_row, int* n_col) {
+    if (!p) return fail(DDN_E_ARG, "null plan");
+    HIPCHK(hipStreamSynchronize(p->stream));
+    auto avg = [](std::vector<EvPair>& v, double* out, int* n) {
+        double tot = 0;
+        for (auto& e : v) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) tot += ms;
+        }
+        if (out) *out = v.empty() ? 0.0 : tot / (double)v.size();
+        if (n) *n = (int)v.size();
+    };
+    avg(p->ev_row, row_ms, n_row);
+    avg(p->ev_col, col_ms, n_col);
+    return DDN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+// Device-side FFT building blocks for gfx950: complex type, small-radix butterflies,
+// in-place LDS passes (decimation in frequency forward, decimation in time inverse) and the
+// digit-reversal maps between natural frequency index and LDS position.
+//
+// Layout convention.  A length-n transform over `C = 1 << cshift` interleaved sequences lives in
+// LDS as element (pos, c) at index SW((pos << cshift) + c).  The forward transform takes natural
+// order to digit-reversed order, the inverse takes digit-reversed order back to natural order,
+// so a forward / pointwise multiply / inverse round trip needs no reordering pass: multiplier
+// arrays are stored once in the same digit-reversed order.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define DDN_MAXPASS 8
+
+template <typename T>
+struct cx {
+    T x, y;
+};
+
+template <typename T>
+__device__ __forceinline__ cx<T> mk(T a, T b) {
+    cx<T> r;
+    r.x = a;
+    r.y = b;
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }
+template <typename T>
+__device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) { return mk<T>(a.x - b.x, a.y - b.y); }
+template <typename T>
+__device__ __forceinline__ cx<T> operator*(cx<T> a, cx<T> b) { return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <typename T>
+__device__ __forceinline__ cx<T> operator*(cx<T> a, T s) { return mk<T>(a.x * s, a.y * s); }
+template <typename T>
+__device__ __forceinline__ cx<T> cconj(cx<T> a) { return mk<T>(a.x, -a.y); }
+// a * conj(b)
+template <typename T>
+__device__ __forceinline__ cx<T> mulc(cx<T> a, cx<T> b) { return mk<T>(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+// multiply by -i (forward rotation) or +i (inverse rotation)
+template <typename T, bool INV>
+__device__ __forceinline__ cx<T> rot90(cx<T> a) {
+    if (INV) return mk<T>(-a.y, a.x);
+    return mk<T>(a.y, -a.x);
+}
+
+// Factorisation of one transform length.  Pass s works on blocks of length m[s]*radix[s];
+// m[s] = n / (radix[0] * ... * radix[s]);  twmul[s] = n / (m[s]*radix[s]).
+struct FftDesc {
+    int n;
+    int npass;
+    int pow2;                 // every radix is a power of two
+    int radix[DDN_MAXPASS];
+    int rshift[DDN_MAXPASS];  // log2(radix) when pow2
+    int m[DDN_MAXPASS];
+    int mshift[DDN_MAXPASS];  // log2(m) when m is a power of two, else -1
+    int twmul[DDN_MAXPASS];
+};
+
+// LDS index swizzle: XOR the low five index bits with two higher bit groups so that the strided
+// accesses of the butterfly passes (strides 16, 32, 256, 1024 ... elements) and the
+// digit-reversed gathers spread over the banks.  A bijection on every aligned block of 32.
+__device__ __forceinline__ int SW(int i) { return i ^ ((i >> 5) & 31) ^ ((i >> 10) & 31); }
+__host__ __device__ __forceinline__ int lds_round(int n) { return (n + 31) & ~31; }
+
+__device__ __forceinline__ int pos_of_freq(const FftDesc& d, int k) {
+    int pos = 0;
+    if (d.pow2) {
+        for (int s = 0; s < d.npass; ++s) {
+            pos += (k & (d.radix[s] - 1)) << d.mshift[s];
+            k >>= d.rshift[s];
+        }
+        return pos;
+    }
+    for (int s = 0; s < d.npass; ++s) {
+        const int r = d.radix[s];
+        const int q = k % r;
+        k /= r;
+        pos += q * d.m[s];
+    }
+    return pos;
+}
+__device__ __forceinline__ int freq_of_pos(const FftDesc& d, int p) {
+    int k = 0, mult = 1;
+    if (d.pow2) {
+        int sh = 0;
+        for (int s = 0; s < d.npass; ++s) {
+            k += ((p >> d.mshift[s]) & (d.radix[s] - 1)) << sh;
+            sh += d.rshift[s];
+        }
+        return k;
+    }
+    for (int s = 0; s < d.npass; ++s) {
+        const int r = d.radix[s];
+        const int q = (p / d.m[s]) % r;
+        k += q * mult;
+        mult *= r;
+    }
+    return k;
+}
+
+// ------------------------------------------------------------------ small DFTs in registers
+template <typename T, int R, bool INV>
+struct Dft;
+
+template <typename T, bool INV>
+struct Dft<T, 2, INV> {
+    static __device__ __forceinline__ void run(cx<T>* v) {
+        cx<T> a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
+    }
+};
+
+template <typename T, bool INV>
+struct Dft<T, 4, INV> {
+    static __device__ __forceinline__ void run(cx<T>* v) {
+        cx<T> t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], t3 = rot90<T, INV>(v[1] - v[3]);
+        v[0] = t0 + t2;
+        v[1] = t1 + t3;
+        v[2] = t0 - t2;
+        v[3] = t1 - t3;
+    }
+};
+
+template <typename T, bool INV>
+struct Dft<T, 8, INV> {
+    static __device__ __forceinline__ void run(cx<T>* v) {
+        cx<T> e[4] = {v[0], v[2], v[4], v[6]};
+        cx<T> o[4] = {v[1], v[3], v[5], v[7]};
+        Dft<T, 4, INV>::run(e);
+        Dft<T, 4, INV>::run(o);
+        const T h = (T)0.70710678118654752440;
+        // w8^1 = (1 -+ i)/sqrt2, w8^2 = -+i, w8^3 = (-1 -+ i)/sqrt2
+        cx<T> o1 = INV ? mk<T>((o[1].x - o[1].y) * h, (o[1].x + o[1].y) * h) : mk<T>((o[1].x + o[1].y) * h, (o[1].y - o[1].x) * h);
+        cx<T> o2 = rot90<T, INV>(o[2]);
+        cx<T> o3 = INV ? mk<T>((-o[3].x - o[3].y) * h, (o[3].x - o[3].y) * h) : mk<T>((o[3].y - o[3].x) * h, (-o[3].x - o[3].y) * h);
+        v[0] = e[0] + o[0];
+        v[4] = e[0] - o[0];
+        v[1] = e[1] + o1;
+        v[5] = e[1] - o1;
+        v[2] = e[2] + o2;
+        v[6] = e[2] - o2;
+        v[3] = e[3] + o3;
+        v[7] = e[3] - o3;
+    }
+};
+
+template <typename T, bool INV>
+struct Dft<T, 16, INV> {
+    static __device__ __forceinline__ void run(cx<T>* v) {
+        cx<T> e[8], o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            e[i] = v[2 * i];
+            o[i] = v[2 * i + 1];
+        }
+        Dft<T, 8, INV>::run(e);
+        Dft<T, 8, INV>::run(o);
+        // w16^k = cos(pi k/8) -+ i sin(pi k/8)
+        const T c[8] = {(T)1.0, (T)0.92387953251128675613, (T)0.70710678118654752440, (T)0.38268343236508977173,
+                        (T)0.0, (T)-0.38268343236508977173, (T)-0.70710678118654752440, (T)-0.92387953251128675613};
+        const T s[8] = {(T)0.0, (T)0.38268343236508977173, (T)0.70710678118654752440, (T)0.92387953251128675613,
+                        (T)1.0, (T)0.92387953251128675613, (T)0.70710678118654752440, (T)0.38268343236508977173};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            cx<T> w = mk<T>(c[k], INV ? s[k] : -s[k]);
+            cx<T> t = (k == 0) ? o[0] : o[k] * w;
+            v[k] = e[k] + t;
+            v[k + 8] = e[k] - t;
+        }
+    }
+};
+
+template <typename T, bool INV>
+struct Dft<T, 3, INV> {
+    static __device__ __forceinline__ void run(cx<T>* v) {
+        const T hs = (T)0.86602540378443864676;
+        cx<T> t1 = v[1] + v[2];
+        cx<T> t2 = mk<T>(v[0].x - (T)0.5 * t1.x, v[0].y - (T)0.5 * t1.y);
+        cx<T> t3 = rot90<T, INV>((v[1] - v[2]) * hs);
+        v[0] = v[0] + t1;
+        v[1] = t2 + t3;
+        v[2] = t2 - t3;
+    }
+};
+
+template <typename T, bool INV>
+struct Dft<T, 5, INV> {
+    static __device__ __forceinline__ void run(cx<T>* v) {
+        const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;
+        const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;
+        cx<T> a1 = v[1] + v[4], a2 = v[2] + v[3], b1 = v[1] - v[4], b2 = v[2] - v[3];
+        cx<T> p1 = mk<T>(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+        cx<T> p2 = mk<T>(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+        cx<T> q1 = rot90<T, INV>(mk<T>(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y));
+        cx<T> q2 = rot90<T, INV>(mk<T>(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y));
+        v[0] = v[0] + a1 + a2;
+        v[1] = p1 + q1;
+        v[4] = p1 - q1;
+        v[2] = p2 + q2;
+        v[3] = p2 - q2;
+    }
+};
+
+// Generic odd prime radix (7, 11, 13): direct O(R^2) evaluation with exact table twiddles.
+// tw is the length-n table exp(-2 pi i e / n) of the enclosing transform, n % R == 0.
+template <typename T, int R, bool INV>
+__device__ __forceinline__ void dft_prime(cx<T>* v, const cx<T>* tw, int n) {
+    cx<T> o[R];
+    const int step = n / R;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        cx<T> acc = v[0];
+#pragma unroll
+        for (int a = 1; a < R; ++a) {
+            cx<T> w = tw[((a * q) % R) * step];
+            acc = acc + (INV ? mulc(v[a], w) : v[a] * w);
+        }
+        o[q] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = o[q];
+}
+
+// One butterfly of pass s on column c: elements base + q*m, q = 0..R-1.
+template <typename T, int R, bool INV>
+__device__ __forceinline__ void butterfly(cx<T>* lds, const cx<T>* tw, int n, int base, int m, int jj, int twmul, int cshift, int c) {
+    cx<T> v[R];
+    int idx[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        idx[q] = SW(((base + q * m) << cshift) + c);
+        v[q] = lds[idx[q]];
+    }
+    if (INV) {
+        if (m > 1) {
+            const int e = jj * twmul;
+#pragma unroll
+            for (int q = 1; q < R; ++q) v[q] = mulc(v[q], tw[q * e]);
+        }
+    }
+    if constexpr (R == 7 || R == 11 || R == 13)
+        dft_prime<T, R, INV>(v, tw, n);
+    else
+        Dft<T, R, INV>::run(v);
+    if (!INV) {
+        if (m > 1) {
+            const int e = jj * twmul;
+#pragma unroll
+            for (int q = 1; q < R; ++q) v[q] = v[q] * tw[q * e];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) lds[idx[q]] = v[q];
+}
+
+// One full pass over `narr` arrays of n * C elements each (array a starts at lds + a*arr_stride).
+template <typename T, bool INV>
+__device__ __forceinline__ void fft_pass(cx<T>* lds, int narr, int arr_stride, const cx<T>* tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
+    const int r = d.radix[s], m = d.m[s], ms = d.mshift[s], twmul = d.twmul[s];
+    const int per = (d.n / r) << cshift;
+    const int total = per * narr;
+    for (int w = tid; w < total; w += nt) {
+        int a = 0, ww = w;
+        if (narr > 1) {
+            a = w / per;
+            ww = w - a * per;
+        }
+        const int c = ww & ((1 << cshift) - 1);
+        const int bf = ww >> cshift;
+        int blk, jj;
+        if (ms >= 0) {
+            blk = bf >> ms;
+            jj = bf & (m - 1);
+        } else {
+            blk = bf / m;
+            jj = bf - blk * m;
+        }
+        const int base = blk * (m * r) + jj;
+        cx<T>* L = lds + a * arr_stride;
+        switch (r) {
+            case 2: butterfly<T, 2, INV>(L, tw, d.n, base, m, jj, twmul, cshift, c); break;
+            case 3: butterfly<T, 3, INV>(L, tw, d.n, base, m, jj, twmul, cshift, c); break;
+            case 4: butterfly<T, 4, INV>(L, tw, d.n, base, m, jj, twmul, cshift, c); break;
+            case 5: butterfly<T, 5, INV>(L, tw, d.n, base, m, jj, twmul, cshift, c); break;
+            case 7: butterfly<T, 7, INV>(L, tw, d.n, base, m, jj, twmul, cshift, c); break;
+            case 8: butterfly<T, 8, INV>(L, tw, d.n, base, m, jj, twmul, cshift, c); break;
+            case 11: butterfly<T, 11, INV>(L, tw, d.n, base, m, jj, twmul, cshift, c); break;
+            case 13: butterfly<T, 13, INV>(L, tw, d.n, base, m, jj, twmul, cshift, c); break;
+            default: butterfly<T, 16, INV>(L, tw, d.n, base, m, jj, twmul, cshift, c); break;
+        }
+    }
+}
+
+// Forward: natural -> digit-reversed.  Caller guarantees the input is visible (barrier before).
+// Ends with a barrier.
+template <typename T>
+__device__ __forceinline__ void fft_forward(cx<T>* lds, int narr, int arr_stride, const cx<T>* tw, const FftDesc& d, int cshift, int tid, int nt) {
+    for (int s = 0; s < d.npass; ++s) {
+        fft_pass<T, false>(lds, narr, arr_stride, tw, d, s, cshift, tid, nt);
+        __syncthreads();
+    }
+}
+// Inverse (unnormalised): digit-reversed -> natural.  Ends with a barrier.
+template <typename T>
+__device__ __forceinline__ void fft_inverse(cx<T>* lds, int narr, int arr_stride, const cx<T>* tw, const FftDesc& d, int cshift, int tid, int nt) {
+    for (int s = d.npass - 1; s >= 0; --s) {
+        fft_pass<T, true>(lds, narr, arr_stride, tw, d, s, cshift, tid, nt);
+        __syncthreads();
+    }
+}

@@ -1,0 +1,180 @@
+"""Spectral operator algebra with the reference's interface
+(deblur_denoise/op_math/python_code/{multiplying_matrix,eig_vals_for_periodic_conv_op,apply_periodic_conv_2d}.py).
+
+Everything is evaluated by libddn on the GPU: eigenvalue arrays come from the library's own 2-D
+transform of the impulse response, operator applications are real-to-complex / complex-to-real
+round trips with Hermitian-symmetrised multipliers.  Results are returned as complex tensors with a
+zero imaginary part where the reference returns complex tensors (its imaginary parts are roundoff).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..plan import Plan, compute_device, real_dtype, stage
+
+
+def _ctype(dt):
+    return torch.complex128 if dt == torch.float64 else torch.complex64
+
+
+def eig_vals_for_periodic_conv_op(filter_kernel, num_rows: int, num_cols: int, **kwargs) -> torch.Tensor:
+    """Eigenvalues (2-D DFT of the impulse response) of the periodic correlation with
+    `filter_kernel`, centred at k//2; the kernel is rounded to float32 first
+    (eig_vals_for_periodic_conv_op.py:5-61).  Returns a num_rows x num_cols complex tensor."""
+    dt = real_dtype(kwargs.get("dtype", torch.float32))
+    dev = compute_device(kwargs.get("device"))
+    out_dev = kwargs.get("device", "cpu")
+    plan = Plan(num_rows, num_cols, 1, dt, dev)
+    try:
+        plan.set_kernel(filter_kernel)
+        e = plan.get_eigK()
+        torch.cuda.synchronize(dev)
+    finally:
+        plan.close()
+    return e.to(out_dev)
+
+
+def apply_periodic_conv_2d(x: torch.Tensor, eig_val_arr: torch.Tensor, **kwargs) -> torch.Tensor:
+    """ifft2(eig_val_arr * fft2(x)) for a real m x n image x (apply_periodic_conv_2d.py:3-28)."""
+    src = x.device
+    dt = real_dtype(x.dtype)
+    dev = compute_device(kwargs.get("device", src))
+    H, W = x.shape
+    plan = Plan(H, W, 1, dt, dev)
+    try:
+        y = plan.apply_multiplier(eig_val_arr, stage(x, dev, dt).reshape(1, H, W))
+    finally:
+        plan.close()
+    return torch.complex(y[0], torch.zeros_like(y[0])).to(src)
+
+
+class DeblurDenoiseOperators:
+    """Operators required for deblurring and denoising (multiplying_matrix.py:6-112).
+
+    kernel: k x k tensor / ndarray; blurred_image: (H, W) tensor (only its shape and dtype are used);
+    tprimaldr, s: the step sizes entering eig_vals_mat = 1 + t^2 |eK|^2 + t^2 |eD1|^2 + t s |eD2|^2.
+    Extensions through keyword arguments: batch (number of images a solver will drive through this
+    plan), dtype, eig_arrays = {"K":..., "D":..., "M":...} to consume externally supplied eigenvalue
+    arrays bit for bit (needed for fp64 parity), tune = {"cols":..,"split":..} column tiling knobs.
+    """
+
+    def __init__(self, kernel, blurred_image, tprimaldr, s=None, device="cpu", **kwargs):
+        self.kernel = kernel
+        self.b = blurred_image
+        self.t = tprimaldr
+        self.s = s if s is not None else tprimaldr
+        self.num_rows, self.num_cols = blurred_image.shape[-2], blurred_image.shape[-1]
+        self.device = device
+        self._dt = real_dtype(kwargs.get("dtype", blurred_image.dtype if isinstance(blurred_image, torch.Tensor) else torch.float32))
+        self._dev = compute_device(device if device != "cpu" else (blurred_image.device if isinstance(blurred_image, torch.Tensor) else None))
+        self._batch = int(kwargs.get("batch", 1))
+        self.plan = Plan(self.num_rows, self.num_cols, self._batch, self._dt, self._dev, tune=kwargs.get("tune"))
+        self._plan1: Optional[Plan] = None
+        self._eig_arrays = kwargs.get("eig_arrays")
+        self._cache = {}
+        self.setup_operators()
+
+    # mm:48-72
+    def setup_operators(self):
+        cK = float(self.t) * float(self.t)
+        cD = float(self.t) * float(self.t) + float(self.t) * float(self.s)
+        ea = self._eig_arrays
+        for pl in self._plans():
+            if ea is not None:
+                pl.set_eig(ea["K"], ea.get("D"))
+                pl.set_resolvent(cK, cD, ea["M"])
+            else:
+                pl.set_kernel(self.kernel)
+                pl.set_resolvent(cK, cD)
+
+    def _plans(self):
+        return [self.plan]
+
+    def _single(self) -> Plan:
+        """Plan for one image, used by the apply_* methods when the solver plan is batched."""
+        if self._batch == 1:
+            return self.plan
+        if self._plan1 is None:
+            self._plan1 = Plan(self.num_rows, self.num_cols, 1, self._dt, self._dev)
+            ea = self._eig_arrays
+            cK = float(self.t) ** 2
+            cD = cK + float(self.t) * float(self.s)
+            if ea is not None:
+                self._plan1.set_eig(ea["K"], ea.get("D"))
+                self._plan1.set_resolvent(cK, cD, ea["M"])
+            else:
+                self._plan1.set_kernel(self.kernel)
+                self._plan1.set_resolvent(cK, cD)
+        return self._plan1
+
+    # ---- eigenvalue arrays in the reference's layout (mm:51-72), materialised on demand
+    @property
+    def eig_arry_K(self):
+        if "K" not in self._cache:
+            self._cache["K"] = self._single().get_eigK().to(self.device)
+        return self._cache["K"]
+
+    @property
+    def eig_arry_D1(self):
+        if "D" not in self._cache:
+            if self._eig_arrays is not None and self._eig_arrays.get("D") is not None:
+                d = torch.as_tensor(self._eig_arrays["D"])
+            else:
+                n = torch.arange(self.num_cols, dtype=torch.float64)
+                row = 1 - torch.exp(-2j * np.pi * n / self.num_cols)
+                d = row.to(_ctype(self._dt))[None, :].expand(self.num_rows, -1).contiguous()
+            self._cache["D"] = d.to(self.device)
+        return self._cache["D"]
+
+    eig_arry_D2 = eig_arry_D1
+
+    @property
+    def eig_arry_KTrans(self): return torch.conj(self.eig_arry_K)
+    @property
+    def eig_arry_D1Trans(self): return torch.conj(self.eig_arry_D1)
+    @property
+    def eig_arry_D2Trans(self): return torch.conj(self.eig_arry_D2)
+
+    @property
+    def eig_vals_mat(self):
+        if self._eig_arrays is not None:
+            return torch.as_tensor(self._eig_arrays["M"]).to(self.device)
+        K, D = self.eig_arry_K, self.eig_arry_D1
+        return (torch.ones((self.num_rows, self.num_cols), device=K.device) + self.t * self.t * torch.conj(K) * K
+                + self.t * self.t * torch.conj(D) * D + self.t * self.s * torch.conj(D) * D)
+
+    # ---- applications (mm:74-112)
+    def _apply(self, op, x):
+        src = x.device
+        xr = x.real if x.is_complex() else x
+        xd = stage(xr, self._dev, self._dt).reshape(1, self.num_rows, self.num_cols)
+        y = self._single().apply(op, xd)[0]
+        if x.is_complex():
+            yi = self._single().apply(op, stage(x.imag, self._dev, self._dt).reshape(1, self.num_rows, self.num_cols))[0]
+            return torch.complex(y, yi).to(src)
+        return torch.complex(y, torch.zeros_like(y)).to(src)
+
+    def apply_K(self, x): return self._apply(L.OP_K, x)
+    def apply_D1(self, x): return self._apply(L.OP_D, x)
+    def apply_D2(self, x): return self._apply(L.OP_D, x)
+    def apply_KTrans(self, x): return self._apply(L.OP_KT, x)
+    def apply_D1Trans(self, x): return self._apply(L.OP_DT, x)
+    def apply_D2Trans(self, x): return self._apply(L.OP_DT, x)
+
+    def apply_D(self, x):
+        return torch.stack([self.apply_D1(x), self.apply_D2(x)], dim=2)
+
+    def apply_DTrans(self, y):
+        return self.apply_D1Trans(y[:, :, 0]) + self.apply_D2Trans(y[:, :, 1])
+
+    def apply_Mat(self, x): return self._apply(L.OP_MAT, x)
+    def invert_matrix(self, x): return self._apply(L.OP_RESOLVENT, x)
+
+    def close(self):
+        self.plan.close()
+        if self._plan1 is not None:
+            self._plan1.close()

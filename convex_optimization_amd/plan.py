@@ -1,0 +1,167 @@
+"""Thin owner of a libddn plan: device selection, tensor staging, pointer plumbing."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def compute_device(device=None) -> torch.device:
+    """The HIP device work runs on.  `device` may be a cuda device; 'cpu'/None select cuda:current."""
+    if not torch.cuda.is_available():
+        raise L.DdnError("no MI355X/HIP device visible: this package has no CPU path")
+    if device is not None:
+        d = torch.device(device)
+        if d.type == "cuda":
+            return d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def real_dtype(dtype) -> torch.dtype:
+    if dtype in (torch.float64, torch.complex128, "float64", "f64"):
+        return torch.float64
+    return torch.float32
+
+
+def stage(x, dev: torch.device, dtype: torch.dtype) -> torch.Tensor:
+    """Contiguous copy of x on the compute device (never aliases caller memory: callers keep ownership)."""
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
+    return x.detach().to(device=dev, dtype=dtype, copy=True).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def taps_array(kernel) -> np.ndarray:
+    if isinstance(kernel, torch.Tensor):
+        k = kernel.detach().cpu().numpy()
+    else:
+        k = np.asarray(kernel)
+    if k.ndim != 2:
+        k = k.reshape(k.shape[-2], k.shape[-1])
+    return np.ascontiguousarray(k, dtype=np.float64)
+
+
+class Plan:
+    def __init__(self, H: int, W: int, batch: int, dtype: torch.dtype, dev: torch.device, tune=None):
+        self.H, self.W, self.batch, self.dtype, self.dev = int(H), int(W), int(batch), dtype, dev
+        self._h = C.c_void_p(0)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            L.check(L.lib().ddn_plan_create(C.byref(self._h), self.H, self.W, self.batch,
+                                            L.F64 if dtype == torch.float64 else L.F32, C.c_void_p(stream)))
+            if tune:
+                L.check(L.lib().ddn_plan_tune(self._h, int(tune.get("cols", 0)), int(tune.get("split", 0)), int(tune.get("row_threads", 0))))
+        self._keep = []
+
+    def close(self):
+        if self._h and self._h.value:
+            L.lib().ddn_plan_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync_stream(self):
+        L.check(L.lib().ddn_plan_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+
+    # ---- operator set-up
+    def set_kernel(self, kernel):
+        k = taps_array(kernel)
+        with torch.cuda.device(self.dev):
+            L.check(L.lib().ddn_plan_set_kernel(self._h, k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], k.shape[1]))
+
+    def _cplx(self, a):
+        if isinstance(a, np.ndarray):
+            a = torch.from_numpy(a)
+        if not a.is_complex():
+            a = a.to(torch.complex128 if a.dtype == torch.float64 else torch.complex64)
+        a = a.detach().to(self.dev).contiguous()
+        return a, (L.C128 if a.dtype == torch.complex128 else L.C64)
+
+    def set_eig(self, eigK, eigD=None):
+        K, ck = self._cplx(eigK)
+        D = None
+        if eigD is not None:
+            D, cd = self._cplx(eigD)
+            if cd != ck:
+                D = D.to(K.dtype)
+        with torch.cuda.device(self.dev):
+            L.check(L.lib().ddn_plan_set_eig(self._h, _ptr(K), _ptr(D), ck))
+            torch.cuda.synchronize(self.dev)
+
+    def set_resolvent(self, cK: float, cD: float, M=None):
+        with torch.cuda.device(self.dev):
+            if M is not None:
+                Mt, cm = self._cplx(M)
+                L.check(L.lib().ddn_plan_set_resolvent(self._h, float(cK), float(cD), _ptr(Mt), cm))
+                torch.cuda.synchronize(self.dev)
+            else:
+                L.check(L.lib().ddn_plan_set_resolvent(self._h, float(cK), float(cD), C.c_void_p(0), 0))
+
+    def get_eigK(self) -> torch.Tensor:
+        ct = torch.complex128 if self.dtype == torch.float64 else torch.complex64
+        out = torch.empty((self.H, self.W), dtype=ct, device=self.dev)
+        with torch.cuda.device(self.dev):
+            L.check(L.lib().ddn_plan_get_eigK(self._h, _ptr(out)))
+        return out
+
+    # ---- applications
+    def apply(self, op: int, x: torch.Tensor) -> torch.Tensor:
+        y = torch.empty_like(x)
+        with torch.cuda.device(self.dev):
+            self.sync_stream()
+            L.check(L.lib().ddn_apply(self._h, op, _ptr(x), _ptr(y)))
+        return y
+
+    def apply_multiplier(self, mult, x: torch.Tensor, conj=False, recip=False) -> torch.Tensor:
+        m, cm = self._cplx(mult)
+        y = torch.empty_like(x)
+        with torch.cuda.device(self.dev):
+            self.sync_stream()
+            L.check(L.lib().ddn_apply_multiplier(self._h, _ptr(m), cm, (1 if conj else 0) | (2 if recip else 0), _ptr(x), _ptr(y)))
+            torch.cuda.synchronize(self.dev)
+        return y
+
+    def circular_convolve2d(self, kernel, image: torch.Tensor) -> torch.Tensor:
+        k = taps_array(kernel)
+        out = torch.empty_like(image)
+        with torch.cuda.device(self.dev):
+            self.sync_stream()
+            L.check(L.lib().ddn_circular_convolve2d(self._h, k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], k.shape[1], _ptr(image), _ptr(out)))
+        return out
+
+    def enable_timing(self, on=True):
+        L.check(L.lib().ddn_plan_enable_timing(self._h, 1 if on else 0))
+
+    def last_timing(self):
+        r, c = C.c_double(0), C.c_double(0)
+        nr, nc = C.c_int(0), C.c_int(0)
+        L.check(L.lib().ddn_plan_last_timing(self._h, C.byref(r), C.byref(c), C.byref(nr), C.byref(nc)))
+        return {"row_ms": r.value, "col_ms": c.value, "n_row": nr.value, "n_col": nc.value}
+
+
+def prox_call(kind: int, x: torch.Tensor, lam: float) -> torch.Tensor:
+    y = torch.empty_like(x)
+    n = x.numel() // 2 if kind == L.PROX_ISO else x.numel()
+    with torch.cuda.device(x.device):
+        L.check(L.lib().ddn_prox(kind, L.F64 if x.dtype == torch.float64 else L.F32, _ptr(x), _ptr(y), n, float(lam),
+                                 C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return y
+
+
+def reduce_call(x: torch.Tensor, y: torch.Tensor, batch: int = 1) -> torch.Tensor:
+    out = torch.empty((batch, 4), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().ddn_reduce(L.F64 if x.dtype == torch.float64 else L.F32, _ptr(x), _ptr(y), x.numel() // batch, batch, _ptr(out),
+                                   C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return out

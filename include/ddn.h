@@ -1,0 +1,180 @@
+/*
+ * ddn.h -- C ABI of libddn, the MI355X (gfx950) implementation of the
+ * deblur_denoise iteration hot path of rahul3/convex_optimization.
+ *
+ * The reference has no native/FFI boundary: its seam is the public Python API.
+ * Each entry point below names the reference function(s) whose work it replaces
+ * (paths relative to the reference root, deblur_denoise/...).  A Python host
+ * (convex_optimization_amd/) binds these with ctypes and keeps the reference's
+ * signatures; see INTEGRATION.md for the stub a maintainer of the reference
+ * would add.
+ *
+ * Conventions
+ *   - every pointer named *_dev is a device pointer (HIP), caller-owned, never
+ *     freed or retained past the call unless stated; images are row-major
+ *     [batch][H][W] real arrays of the plan's dtype; 3-component duals are
+ *     [3][batch][H][W] (component-major), exactly torch.stack((a,b,c)) for batch 1;
+ *   - return value 0 = success, negative = error (see DDN_E_*); the message is
+ *     available from ddn_last_error() (thread-local); nothing throws across the ABI;
+ *   - a plan is bound to one device and one stream and is not thread-safe;
+ *     all work is enqueued on that stream and is asynchronous unless stated.
+ */
+#ifndef DDN_H
+#define DDN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDN_OK 0
+#define DDN_E_ARG (-1)       /* bad shape / dtype / enum / null pointer          */
+#define DDN_E_UNSUPPORTED (-2) /* size with a prime factor > 13, too large for LDS */
+#define DDN_E_HIP (-3)       /* a HIP runtime call failed                         */
+#define DDN_E_STATE (-4)     /* plan not set up for the requested operation       */
+
+/* dtype */
+#define DDN_F32 0
+#define DDN_F64 1
+/* complex dtype of arrays handed in from the host framework */
+#define DDN_C64 0
+#define DDN_C128 1
+
+/* objective of the data term (cp:69-74, admm:99-104, pdr:101-110) */
+#define DDN_OBJ_L1 0
+#define DDN_OBJ_L2 1
+
+/* loss kinds computed on device every iteration (core/loss.py:5-36,112-117) */
+#define DDN_LOSS_NONE 0
+#define DDN_LOSS_L1 1
+#define DDN_LOSS_L2 2
+#define DDN_LOSS_MSE 3
+#define DDN_LOSS_PSNR 4
+
+/* spectral operators for ddn_apply (op_math/python_code/multiplying_matrix.py:74-112) */
+#define DDN_OP_K 0          /* apply_K           mm:74-76   */
+#define DDN_OP_KT 1         /* apply_KTrans      mm:86-88   */
+#define DDN_OP_D 2          /* apply_D1 == apply_D2  mm:78-84 (both are the horizontal backward difference) */
+#define DDN_OP_DT 3         /* apply_D1Trans == apply_D2Trans mm:90-96 */
+#define DDN_OP_RESOLVENT 4  /* invert_matrix     mm:110-112 */
+#define DDN_OP_MAT 5        /* apply_Mat         mm:106-108 */
+
+/* prox kinds (core/proximal_operators.py:4-57) */
+#define DDN_PROX_L1 0
+#define DDN_PROX_L2SQ 1
+#define DDN_PROX_ISO 2
+#define DDN_PROX_BOX 3
+#define DDN_PROX_L2 4
+
+typedef struct ddn_plan ddn_plan;
+
+int ddn_version(void);
+const char* ddn_last_error(void);
+
+/* Replaces DeblurDenoiseOperators.__init__ (mm:10-46) for `batch` images of H x W.
+ * Allocates twiddle tables, spectral scratch (2 half-spectra per image) and the
+ * per-iteration loss buffers.  `stream` is a hipStream_t (NULL = default stream). */
+int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* stream);
+int ddn_plan_destroy(ddn_plan* p);
+int ddn_plan_set_stream(ddn_plan* p, void* stream);
+
+/* Column-stage tiling knobs (0 = heuristic): number of columns per workgroup and the
+ * split H = A x B of the column transform (A = 1: one pass).  For experiments. */
+int ddn_plan_tune(ddn_plan* p, int cols_per_block, int split_A, int row_threads);
+
+/* Replaces eig_vals_for_periodic_conv_op (eig_vals_for_periodic_conv_op.py:5-61) and
+ * setup_operators (mm:48-72): builds, on the device, the eigenvalue array of the
+ * periodic correlation with `taps` (host, row-major kh x kw, rounded to float32 as
+ * eig:49 does), centred at (kh/2, kw/2), and of D = [[-1, 1]].  */
+int ddn_plan_set_kernel(ddn_plan* p, const double* taps_host, int kh, int kw);
+
+/* Injects eigenvalue arrays exactly as the reference holds them (device, H x W
+ * complex, natural index order; mm:51-59).  eigD may be NULL (analytic 1 - w^k is
+ * used).  Needed for fp64 parity, where the reference's complex64-rounded arrays
+ * must be consumed bit for bit.  Selects row-spectral D/D^T in the solvers. */
+int ddn_plan_set_eig(ddn_plan* p, const void* eigK_dev, const void* eigD_dev, int cdtype);
+
+/* Resolvent multiplier (mm:67-72, 110-112):  1 / (1 + cK |eK|^2 + cD |eD|^2)  with
+ * cK = t*t, cD = t*t + t*s; or, when M_dev != NULL, the reciprocal of the injected
+ * `eig_vals_mat` (device, H x W complex, natural order). */
+int ddn_plan_set_resolvent(ddn_plan* p, double cK, double cD, const void* M_dev, int cdtype);
+
+/* Exports the eigenvalue array of K in the reference's layout (device, H x W complex,
+ * natural order, complex64 for a float32 plan / complex128 for float64). */
+int ddn_plan_get_eigK(ddn_plan* p, void* out_dev);
+
+/* y = real(ifft2(e * fft2(x))) for a built-in operator (apply_periodic_conv_2d.py:28
+ * via mm:74-112).  x, y: [batch][H][W]; may alias. */
+int ddn_apply(ddn_plan* p, int op, const void* x_dev, void* y_dev);
+
+/* y = real(ifft2(mult * fft2(x))) with an arbitrary multiplier (device, H x W complex,
+ * natural order) -- apply_periodic_conv_2d.py:3-28 with a caller-supplied eigen array;
+ * flags bit0: use conj(mult); bit1: use 1/mult. */
+int ddn_apply_multiplier(ddn_plan* p, const void* mult_dev, int cdtype, int flags, const void* x_dev, void* y_dev);
+
+/* circular_convolve2d (core/convolution.py:22-52): FFT circular convolution with the
+ * float32 zero-padded kernel rolled by (-kh//2, -kw//2).  image/out: [batch][H][W]. */
+int ddn_circular_convolve2d(ddn_plan* p, const double* taps_host, int kh, int kw, const void* image_dev, void* out_dev);
+
+/* Elementwise proximal maps (core/proximal_operators.py:4-57) on n elements.
+ * ISO: x and y are [2][n] (prox:22-50).  L2 (prox:10-14) uses the whole-tensor norm. */
+int ddn_prox(int kind, int dtype, const void* x_dev, void* y_dev, size_t n, double lambda, void* stream);
+
+/* l1_loss / l2_loss / mse / psnr (core/loss.py:5-36,112-117) of x - y per image.
+ * out4_dev: [batch][4] doubles = {sum|d|, sqrt(sum d^2), mean d^2, 10 log10(1/mse)}. */
+int ddn_reduce(int dtype, const void* x_dev, const void* y_dev, size_t n_per_image, int batch, double* out4_dev, void* stream);
+
+/* ---- solver loops -------------------------------------------------------------
+ * Each *_run advances the iterate arrays in place by up to n_iters iterations of the
+ * reference loop body.  Per iteration the device records, per image, the four loss
+ * values of (iterate - reference image) in loss_ring_dev[iter][image][8] (doubles;
+ * entries 0..3 = l1,l2,mse,psnr of the solver's primary pair, 4..7 = secondary pair,
+ * see each solver) when loss_ring_dev != NULL.  When tol_kind != DDN_LOSS_NONE an
+ * image whose loss value (of that kind, primary pair) drops below `tol` after an
+ * iteration is frozen at that iteration (the reference's `break`), without a host
+ * round trip; iters_done_dev[image] (int32, may be NULL) receives the number of
+ * iterations applied.
+ */
+
+/* chambolle_pock loop body cp:58-92.  x,z: [batch][H][W]; y: [3][batch][H][W]; b: [batch][H][W].
+ * Loss pair: (x_next, b) (cp:96). No early stop in the reference (tol_kind ignored). */
+int ddn_cp_run(ddn_plan* p, void* x_dev, void* z_dev, void* y_dev, const void* b_dev,
+               double t, double s, double gamma, int objective, int n_iters,
+               double* loss_ring_dev);
+
+/* admm_solver loop body admm:69-115 and final solve admm:160-173.
+ * u,w: [batch][H][W]; y,z: [3][batch][H][W]; sol_out: [batch][H][W] receives the
+ * solution the reference returns.  Loss pair: (sol, b) where sol is the look-ahead
+ * solve of admm:118-132; iteration i's value is recorded at ring slot i.
+ * first_loss_iter: iterations < first_loss_iter are not tested against tol. */
+int ddn_admm_run(ddn_plan* p, void* u_dev, void* w_dev, void* y_dev, void* z_dev, const void* b_dev,
+                 double t, double rho, double gamma, int objective, int n_iters,
+                 int tol_kind, double tol, int first_loss_iter,
+                 double* loss_ring_dev, int* iters_done_dev, void* sol_out_dev);
+
+/* primal_dr_splitting loop body pdr:94-129.  z1: [batch][H][W]; z2: [3][batch][H][W].
+ * Primary loss pair: (z1, z1prev) (pdr:144); secondary: (z1, b) (pdr:145-149). */
+int ddn_pdr_run(ddn_plan* p, void* z1_dev, void* z2_dev, const void* b_dev,
+                double t, double rho, double gamma, int objective, int n_iters,
+                int tol_kind, double tol, int first_loss_iter,
+                double* loss_ring_dev, int* iters_done_dev);
+
+/* primal_dual_dr_splitting loop body pddr:65-101.  p: [batch][H][W]; q: [3][batch][H][W].
+ * Loss pair: (clip(p), b) (pddr:104). */
+int ddn_pddr_run(ddn_plan* p, void* p_dev, void* q_dev, const void* b_dev,
+                 double t, double rho, double gamma, int n_iters,
+                 int tol_kind, double tol, int first_loss_iter,
+                 double* loss_ring_dev, int* iters_done_dev);
+
+/* Timing hook for bench.py: average duration in milliseconds, measured with HIP
+ * events on the plan's stream, of the last *_run call's dominant kernel (the fused
+ * row kernel) and of all its kernels; synchronises the stream. */
+int ddn_plan_last_timing(ddn_plan* p, double* row_kernel_ms_avg, double* col_kernel_ms_avg, int* n_row_launches, int* n_col_launches);
+int ddn_plan_enable_timing(ddn_plan* p, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDN_H */

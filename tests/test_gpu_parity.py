@@ -1,0 +1,310 @@
+"""GPU parity tests: the HIP path (through the C ABI of libddn, via the Python host that mirrors the
+reference API) against (1) golden vectors produced by the reference itself and (2) the CPU oracle on
+the same seeded inputs.  Tolerances: fp32 relative L2 <= 1e-5, fp64 <= 1e-11 on solver iterates
+(the north-star contract); single operator applications are held to a few float32 ulps."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ddn_oracle as O  # checker only
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import convex_optimization_amd as pkg
+    from convex_optimization_amd import _lib
+    _lib.lib()  # fails loudly if the HIP library is missing
+    assert torch.cuda.is_available()
+    return pkg
+
+
+def rel(a, b):
+    return O.rel_l2(np.asarray(a), np.asarray(b))
+
+
+def test_eigen_arrays(pkg, golden_dir):
+    g = _load(golden_dir, "eigen.npz")
+    k = _load(golden_dir, "kernels.npz")
+    for kname in ["gauss5", "gauss9", "gauss10", "motion15_45", "motion5_30"]:
+        for (H, W) in [(32, 32), (64, 64), (48, 80)]:
+            e = pkg.eig_vals_for_periodic_conv_op(k[kname], H, W).numpy()
+            assert e.shape == (H, W) and e.dtype == np.complex64
+            np.testing.assert_allclose(e, g[f"{kname}_{H}x{W}_K"], rtol=0, atol=3e-7, err_msg=f"{kname} {H}x{W}")
+
+
+def test_operator_applications(pkg, golden_dir):
+    g = _load(golden_dir, "operators.npz")
+    k = _load(golden_dir, "kernels.npz")
+    for kname in ["gauss9", "motion15_45", "gauss10"]:
+        for (H, W) in [(64, 64), (48, 80)]:
+            tag = f"{kname}_{H}x{W}"
+            x = torch.from_numpy(g[tag + "_x"]); y2 = torch.from_numpy(g[tag + "_y2"])
+            op = pkg.DeblurDenoiseOperators(k[kname], x, 2.0, 0.5)
+            for nm, val in [("K", op.apply_K(x)), ("KT", op.apply_KTrans(x)), ("D1", op.apply_D1(x)),
+                            ("D1T", op.apply_D1Trans(x)), ("D", op.apply_D(x)), ("DT", op.apply_DTrans(y2)),
+                            ("inv", op.invert_matrix(x)), ("Mat", op.apply_Mat(x))]:
+                ref = g[f"{tag}_{nm}"]
+                assert val.is_complex() and tuple(val.shape) == ref.shape
+                np.testing.assert_allclose(val.numpy().real, ref.real, rtol=0, atol=4e-6, err_msg=f"{tag} {nm}")
+            np.testing.assert_allclose(op.eig_vals_mat.numpy().real, g[tag + "_eigM"].real, rtol=3e-6, atol=3e-6)
+            op.close()
+
+
+def test_prox(pkg, golden_dir):
+    from convex_optimization_amd.core import prox_l1, prox_l2, prox_l2_squared, prox_iso, prox_box
+    g = _load(golden_dir, "prox.npz")
+    x = torch.from_numpy(g["x"]); x2 = torch.from_numpy(g["x2"])
+    for dev in ["cpu", "cuda"]:
+        for i in range(3):
+            lam = float(g[f"lam{i}"])
+            assert np.array_equal(prox_l1(x.to(dev), lam).cpu().numpy(), g[f"l1_{i}"])
+            assert np.array_equal(prox_box(x.to(dev), lam).cpu().numpy(), g[f"box_{i}"])
+            np.testing.assert_allclose(prox_l2_squared(x.to(dev), lam).cpu().numpy(), g[f"l2sq_{i}"], rtol=2e-7)
+            np.testing.assert_allclose(prox_iso(x2.to(dev), lam).cpu().numpy(), g[f"iso_{i}"], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(prox_l2(x.to(dev), lam).cpu().numpy(), g[f"l2_{i}"], rtol=1e-6, atol=1e-7)
+    e = torch.from_numpy(g["edge"])
+    assert np.array_equal(prox_l1(e, 0.5).numpy(), g["edge_l1"])
+    assert np.array_equal(prox_box(e, 0.5).numpy(), g["edge_box"])
+    e2 = torch.from_numpy(g["edge2"])
+    np.testing.assert_allclose(prox_iso(e2, 5.0).numpy(), g["edge2_iso5"], rtol=1e-6)
+    assert prox_iso(e2, 5.0).numpy()[0, 0, 1] == 0  # norm == lambda -> 0 (strict >)
+    np.testing.assert_allclose(prox_iso(e2, 0.5).numpy(), g["edge2_iso05"], rtol=1e-6)
+    assert prox_l1(torch.zeros(0), 0.1).numel() == 0  # empty input
+    # fp64
+    xd = x.double()
+    np.testing.assert_allclose(prox_iso(x2.double(), 0.05).numpy(), O.prox_iso(x2.double(), 0.05).numpy(), rtol=1e-14)
+    assert np.array_equal(prox_l1(xd, 0.05).numpy(), O.prox_l1(xd, 0.05).numpy())
+
+
+def test_circular_convolve(pkg, golden_dir):
+    from convex_optimization_amd.core import circular_convolve2d
+    g = _load(golden_dir, "circconv.npz")
+    k = _load(golden_dir, "kernels.npz")
+    for kname in ["gauss9", "gauss10", "motion15_45", "motion5_30"]:
+        for (H, W) in [(32, 32), (48, 80)]:
+            tag = f"{kname}_{H}x{W}"
+            out = circular_convolve2d(torch.from_numpy(g[tag + "_img"]), torch.from_numpy(k[kname]))
+            np.testing.assert_allclose(out.numpy(), g[tag + "_out"], atol=2e-6, err_msg=tag)
+            delta = torch.zeros(1, H, W); delta[0, 3, 5] = 1.0
+            np.testing.assert_allclose(circular_convolve2d(delta, k[kname]).numpy(), g[tag + "_delta"], atol=2e-6)
+
+
+def test_losses(pkg, golden_dir):
+    from convex_optimization_amd.core import l1_loss, l2_loss, mse, psnr, ssim
+    g = _load(golden_dir, "loss.npz")
+    a = torch.from_numpy(g["a"]); b = torch.from_numpy(g["b"])
+    for nm, fn in [("l1_loss", l1_loss), ("l2_loss", l2_loss), ("mse", mse), ("psnr", psnr), ("ssim", ssim)]:
+        np.testing.assert_allclose(np.asarray(fn(a, b)).reshape(-1), g[nm], rtol=2e-6, err_msg=nm)
+        np.testing.assert_allclose(np.asarray(fn(a.cuda(), b.cuda()).cpu()).reshape(-1), g[nm], rtol=2e-6, err_msg=nm)
+    assert np.isinf(float(psnr(a, a)))
+
+
+def _t(a, dt):
+    return torch.from_numpy(np.asarray(a)).to(dt)
+
+
+CASES32 = [("gauss9", "64x64", [1, 2, 5, 20, 100, 500]), ("motion15_45", "64x64", [1, 5, 20, 100, 500]), ("gauss5", "48x80", [1, 5, 20])]
+
+
+@pytest.mark.parametrize("kname,shape,Ns", CASES32)
+def test_solver_trajectories_fp32(pkg, golden_dir, kname, shape, Ns):
+    """fp32 iterates vs the reference's own iterates (golden), identical b / kernel / initial state.
+    Contract: relative L2 <= 1e-5 after N iterations (Chambolle-Pock with the reference's unstable
+    default steps only up to N = 20)."""
+    g = _load(golden_dir, f"traj_f32_{kname}_{shape}.npz")
+    dt = torch.float32
+    b = _t(g["b"], dt); kern = g["kernel"]
+    TOL = 1e-5
+    worst = {}
+    for N in Ns:
+        st = (_t(g["cp_x0"], dt), _t(g["cp_z0"], dt), _t(g["cp_y0"], dt))
+        x = pkg.chambolle_pock_solver(b[None], kern, t=0.3, s=0.3, max_iter=N + 1, init_state=st)
+        assert tuple(x.shape) == (1,) + tuple(b.shape)
+        worst[f"cp_l1_{N}"] = rel(x.numpy(), g[f"cpstab_l1_N{N}"])
+        x = pkg.chambolle_pock_solver(b[None], kern, objective_function="l2", t=0.3, s=0.3, max_iter=N + 1, init_state=st)
+        worst[f"cp_l2_{N}"] = rel(x.numpy(), g[f"cpstab_l2_N{N}"])
+        st = (_t(g["admm_u0"], dt), _t(g["admm_w0"], dt), _t(g["admm_y0"], dt), _t(g["admm_z0"], dt))
+        for obj in ["l1", "l2"]:
+            x = pkg.admm_solver(b, obj, kernel=kern, niters=N + 1, tol=-1.0, init_state=st)
+            assert tuple(x.shape) == tuple(b.shape)
+            worst[f"admm_{obj}_{N}"] = rel(x.numpy(), g[f"admm_{obj}_N{N}"])
+        for prob in ["l1", "l2"]:
+            x = pkg.primal_dr_splitting(prob, kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0)
+            worst[f"pdr_{prob}_{N}"] = rel(x.numpy(), g[f"pdr_{prob}_N{N}"])
+        st = (_t(g["pddr_p0"], dt), _t(g["pddr_q0"], dt))
+        x = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=st, tol=-1.0)
+        worst[f"pddr_{N}"] = rel(x.numpy(), g[f"pddr_N{N}"])
+    for N in [n for n in Ns if n <= 20]:
+        st = (_t(g["cp_x0"], dt), _t(g["cp_z0"], dt), _t(g["cp_y0"], dt))
+        x = pkg.chambolle_pock_solver(b[None], kern, max_iter=N + 1, init_state=st)
+        worst[f"cpdef_{N}"] = rel(x.numpy(), g[f"cpdef_l1_N{N}"])
+    print({k: f"{v:.2e}" for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not v < TOL}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("kname", ["gauss9", "motion15_45"])
+def test_solver_trajectories_fp64(pkg, golden_dir, kname):
+    """fp64 iterates vs the reference run in float64; the reference's complex64-derived eigenvalue
+    arrays (captured in the fixture) are consumed bit for bit.  Contract: relative L2 <= 1e-11."""
+    g = _load(golden_dir, f"traj_f64_{kname}_64x64.npz")
+    dt = torch.float64
+    b = _t(g["b"], dt); kern = g["kernel"]
+    TOL = 1e-11
+    ea1 = {"K": g["eigK"], "D": g["eigD"], "M": g["M_t1_s1"]}
+    ea2 = {"K": g["eigK"], "D": g["eigD"], "M": g["M_pdr_t2"]}
+    ea3 = {"K": g["eigK"], "D": g["eigD"], "M": g["M_pddr_t3"]}
+    worst = {}
+    for N in [1, 5, 20, 100, 500]:
+        st = (_t(g["cp_x0"], dt), _t(g["cp_z0"], dt), _t(g["cp_y0"], dt))
+        x = pkg.chambolle_pock_solver(b[None], kern, t=0.3, s=0.3, max_iter=N + 1, init_state=st, eig_arrays=ea1)
+        worst[f"cp_{N}"] = rel(x.numpy(), g[f"cpstab_l1_N{N}"])
+        st = (_t(g["admm_u0"], dt), _t(g["admm_w0"], dt), _t(g["admm_y0"], dt), _t(g["admm_z0"], dt))
+        for obj in ["l1", "l2"]:
+            x = pkg.admm_solver(b, obj, kernel=kern, niters=N + 1, tol=-1.0, init_state=st, eig_arrays=ea1)
+            worst[f"admm_{obj}_{N}"] = rel(x.numpy(), g[f"admm_{obj}_N{N}"])
+        for prob in ["l1", "l2"]:
+            x = pkg.primal_dr_splitting(prob, kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0, eig_arrays=ea2)
+            worst[f"pdr_{prob}_{N}"] = rel(x.numpy(), g[f"pdr_{prob}_N{N}"])
+        st = (_t(g["pddr_p0"], dt), _t(g["pddr_q0"], dt))
+        x = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=st, tol=-1.0, eig_arrays=ea3)
+        worst[f"pddr_{N}"] = rel(x.numpy(), g[f"pddr_N{N}"])
+    for N in [20, 100]:
+        st = (_t(g["cp_x0"], dt), _t(g["cp_z0"], dt), _t(g["cp_y0"], dt))
+        x = pkg.chambolle_pock_solver(b[None], kern, max_iter=N + 1, init_state=st, eig_arrays=ea1)
+        worst[f"cpdef_{N}"] = rel(x.numpy(), g[f"cpdef_l1_N{N}"])
+    print({k: f"{v:.2e}" for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not v < TOL}
+    assert not bad, bad
+
+
+def test_loss_sequences_and_rng_replay(pkg, golden_dir):
+    """Device-side per-iteration loss values and the seeded initial iterates match the reference."""
+    g = _load(golden_dir, "traj_f32_gauss9_64x64.npz")
+    b = _t(g["b"], torch.float32); kern = g["kernel"]
+    mse = pkg.core.mse
+    x, losses = pkg.primal_dr_splitting("l1", kern, b, niters=20, loss_function=mse, tol=-1.0, return_losses=True)
+    ref = list(g["pdr_l1_N20_mse"]); ref = ref[2:15] + ref[16:-1]
+    np.testing.assert_allclose(losses, ref, rtol=2e-4)
+    torch.manual_seed(7)
+    x, losses = pkg.chambolle_pock_solver(b[None], kern, t=0.3, s=0.3, max_iter=21, loss_function=mse, return_losses=True)
+    assert rel(x.numpy(), g["cpstab_l1_N20"]) < 1e-5
+    np.testing.assert_allclose(losses, g["cpstab_l1_N20_mse"], rtol=2e-4)
+    torch.manual_seed(7)
+    x, losses = pkg.admm_solver(b, "l1", kernel=kern, niters=21, tol=-1.0, loss_function=mse, return_losses=True)
+    assert rel(x.numpy(), g["admm_l1_N20"]) < 1e-5
+    np.testing.assert_allclose(losses, g["admm_l1_N20_mse"], rtol=2e-4)
+    torch.manual_seed(7)
+    x, losses = pkg.primal_dual_dr_splitting(b, kern, niters=21, loss_function=mse, tol=-1.0, return_losses=True)
+    assert rel(x.numpy(), g["pddr_N20"]) < 1e-5
+    np.testing.assert_allclose(losses, g["pddr_N20_mse"], rtol=2e-4)
+    # arbitrary callables take the per-iteration host path and give the same iterates
+    x2, l2 = pkg.primal_dr_splitting("l1", kern, b, niters=20, loss_function=lambda a, c: O.mse(a, c), tol=-1.0, return_losses=True)
+    assert rel(x2.numpy(), g["pdr_l1_N20"]) < 1e-5
+    np.testing.assert_allclose(l2, ref, rtol=2e-4)
+    with pytest.raises(ValueError):
+        pkg.chambolle_pock_solver(b[None], kern, objective_function="huber", max_iter=3)
+    with pytest.raises(ValueError):
+        pkg.admm_solver(b, "huber", kernel=kern, niters=3)
+
+
+def test_early_stop_matches_oracle(pkg, golden_dir):
+    """The device-side stop freezes an image at the same iteration as the reference's `break`."""
+    g = _load(golden_dir, "traj_f32_gauss9_64x64.npz")
+    b = _t(g["b"], torch.float32); kern = torch.from_numpy(g["kernel"])
+    # primal DR: loss(z1, z1prev) = mse drops below 2e-4 after a handful of iterations
+    ol = []
+    xo = O.primal_dr_splitting("l1", kern, b, niters=60, loss_function=O.mse, tol=2e-4, losses=ol)
+    x, losses = pkg.primal_dr_splitting("l1", kern, b, niters=60, loss_function=pkg.core.mse, tol=2e-4, return_losses=True)
+    assert len(losses) == len(ol) and len(ol) < 40
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    # ADMM: the look-ahead solution is returned when its loss drops below tol
+    st = (_t(g["admm_u0"], torch.float32), _t(g["admm_w0"], torch.float32), _t(g["admm_y0"], torch.float32), _t(g["admm_z0"], torch.float32))
+    ol = []
+    xo = O.admm_solver(b, "l1", t=18, rho=0.001, gamma=0.5, kernel=kern, niters=40, tol=2.2e-2, loss_function=O.mse, init_state=st, losses=ol)
+    x, losses = pkg.admm_solver(b, "l1", kernel=kern, niters=40, tol=2.2e-2, loss_function=pkg.core.mse, init_state=st, return_losses=True)
+    assert len(losses) == len(ol)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+
+
+def test_config2_512_all_solvers_vs_oracle(pkg, golden_dir):
+    """512 x 512, 9x9 Gaussian + noise (BASELINE config 2): HIP path vs the CPU oracle, N = 20."""
+    k = _load(golden_dir, "kernels.npz")
+    kern = torch.from_numpy(k["gauss9"])
+    torch.manual_seed(0)
+    img = torch.rand(1, 512, 512)
+    b = O.add_gaussian_noise(O.circular_convolve2d(img, kern), 0.0, 0.1)[0]
+    N = 20
+    torch.manual_seed(7)
+    st = (torch.rand(512, 512), torch.rand(512, 512), torch.rand(3, 512, 512))
+    xo = O.chambolle_pock(b[None], kern, max_iter=N + 1, init_state=st)
+    x = pkg.chambolle_pock_solver(b[None], kern, max_iter=N + 1, init_state=st)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    stA = tuple(torch.clamp(torch.randn(s, dtype=torch.float32), 0, 1) for s in [(512, 512), (512, 512), (3, 512, 512), (3, 512, 512)])
+    xo = O.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA)
+    x = pkg.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    xo = O.primal_dr_splitting("l1", kern, b, niters=N)
+    x = pkg.primal_dr_splitting("l1", kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    stP = (torch.rand(512, 512), torch.rand(3, 512, 512))
+    xo = O.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP)
+    x = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP, tol=-1.0)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+
+
+def test_batch_equals_loop_of_single_calls(pkg, golden_dir):
+    k = _load(golden_dir, "kernels.npz")
+    kern = k["gauss9"]
+    torch.manual_seed(3)
+    b = torch.rand(3, 64, 96)
+    xb = pkg.primal_dr_splitting("l1", kern, b, niters=12, loss_function=pkg.core.mse, tol=-1.0)
+    assert tuple(xb.shape) == (3, 64, 96)
+    for i in range(3):
+        xi = pkg.primal_dr_splitting("l1", kern, b[i], niters=12, loss_function=pkg.core.mse, tol=-1.0)
+        assert np.array_equal(xb[i].numpy(), xi.numpy())
+    p0 = torch.rand(3, 64, 96); q0 = torch.rand(3, 3, 64, 96)
+    xb = pkg.primal_dual_dr_splitting(b, kern, niters=9, init_state=(p0, q0), tol=-1.0)
+    for i in range(3):
+        xi = pkg.primal_dual_dr_splitting(b[i], kern, niters=9, init_state=(p0[i], q0[:, i]), tol=-1.0)
+        assert np.array_equal(xb[i].numpy(), xi.numpy())
+
+
+@pytest.mark.parametrize("shape", [(4096, 4096), (1024, 1024), (100, 100), (300, 500), (2048, 512)])
+def test_operator_identities_at_size(pkg, golden_dir, shape):
+    """Size-independent properties at full benchmark sizes: adjointness <Kx,y> = <x,K^T y>,
+    <Dx,y> = <x,D^T y>, the resolvent inverts (I + t^2 A^T A), K against a direct correlation on a
+    sub-block, and D against the closed-form stencil."""
+    k = _load(golden_dir, "kernels.npz")
+    kern = k["motion15_45"]
+    H, W = shape
+    torch.manual_seed(1)
+    x = torch.rand(H, W, device="cuda"); y = torch.rand(H, W, device="cuda")
+    t = 1.0
+    op = pkg.DeblurDenoiseOperators(kern, x, t, t, device="cuda")
+    Kx = op.apply_K(x).real; KTy = op.apply_KTrans(y).real
+    lhs, rhs = (Kx.double() * y.double()).sum().item(), (x.double() * KTy.double()).sum().item()
+    assert abs(lhs - rhs) <= 2e-6 * abs(lhs)
+    Dx = op.apply_D1(x).real; DTy = op.apply_D1Trans(y).real
+    assert torch.equal(Dx, x - torch.roll(x, 1, 1)) and torch.equal(DTy, y - torch.roll(y, -1, 1))
+    # resolvent: M^-1 (x + K^T K x + D^T D x) == x   (apply_Mat is exactly I + K^T K + 2 D^T D at t = s = 1)
+    back = op.invert_matrix(op.apply_Mat(x).real).real
+    assert rel(back.cpu().numpy(), x.cpu().numpy()) < 5e-6
+    # K against the direct circular correlation on a 32 x 32 corner (wrap-around included)
+    kk = torch.from_numpy(kern.astype(np.float32)).cuda()
+    kh, kw = kk.shape
+    ref = torch.zeros(32, 32, device="cuda", dtype=torch.float64)
+    for u in range(kh):
+        for v in range(kw):
+            if kk[u, v] != 0:
+                ref += kk[u, v].double() * torch.roll(x, (-(u - kh // 2), -(v - kw // 2)), (0, 1))[:32, :32].double()
+    assert (Kx[:32, :32].double() - ref).abs().max().item() < 3e-6
+    op.close()

@@ -14,23 +14,18 @@
 
 #include "../../include/ddn.h"
 #include "ddn_kernels.hpp"
+#include "ddn_launch.hpp"
+
+#define DDN_DECL_ROW(T)                                                                                              \
+    extern template int row_launch<T, PdrP<T>>(hipStream_t, int, int, size_t, int, const RowCommon<T>&, const PdrP<T>::Args&);   \
+    extern template int row_launch<T, PddrP<T>>(hipStream_t, int, int, size_t, int, const RowCommon<T>&, const PddrP<T>::Args&); \
+    extern template int row_launch<T, AdmmP<T>>(hipStream_t, int, int, size_t, int, const RowCommon<T>&, const AdmmP<T>::Args&); \
+    extern template int cp_launch<T>(hipStream_t, int, int, size_t, int, const RowCommon<T>&, const CpArgs<T>&);
+DDN_DECL_ROW(float)
+DDN_DECL_ROW(double)
 
 namespace {
 
-thread_local std::string g_err;
-
-int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
-}
-
-#define HIPCHK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) return fail(DDN_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-constexpr size_t kLdsMax = 160 * 1024;
 
 // ------------------------------------------------------------------------------ factorisation
 bool factorize(int n, FftDesc& d) {
@@ -116,25 +111,21 @@ bool factorize(int n, FftDesc& d) {
 
 template <typename T>
 int make_table(int n, cx<T>** out) {
-    std::vector<cx<T>> h(n);
-    for (int e = 0; e < n; ++e) {
-        const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)e / (long double)n;
-        h[e].x = (T)cosl(ang);
-        h[e].y = (T)sinl(ang);
-    }
-    HIPCHK(hipMalloc((void**)out, sizeof(cx<T>) * (size_t)n));
-    HIPCHK(hipMemcpy(*out, h.data(), sizeof(cx<T>) * (size_t)n, hipMemcpyHostToDevice));
-    return DDN_OK;
-}
-
-std::mutex g_attr_mu;
-std::set<const void*> g_attr_done;
-
-int ensure_lds_attr(const void* fn) {
-    std::lock_guard<std::mutex> lk(g_attr_mu);
-    if (g_attr_done.count(fn)) return DDN_OK;
-    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
-    g_attr_done.insert(fn);
+    // layout read by tw_setup(): [direct n][hi tw_hi_entries(n)][lo 64]
+    const int nh = tw_hi_entries(n);
+    std::vector<cx<T>> h((size_t)n + nh + 64);
+    auto w = [&](long e) {
+        const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)(e % n) / (long double)n;
+        cx<T> r;
+        r.x = (T)cosl(ang);
+        r.y = (T)sinl(ang);
+        return r;
+    };
+    for (int e = 0; e < n; ++e) h[e] = w(e);
+    for (int k = 0; k < nh; ++k) h[n + k] = w(64L * k);
+    for (int k = 0; k < 64; ++k) h[n + nh + k] = w(k);
+    HIPCHK(hipMalloc((void**)out, sizeof(cx<T>) * h.size()));
+    HIPCHK(hipMemcpy(*out, h.data(), sizeof(cx<T>) * h.size(), hipMemcpyHostToDevice));
     return DDN_OK;
 }
 
@@ -145,14 +136,16 @@ struct EvPair {
 }  // namespace
 
 struct ddn_plan {
-    int H = 0, W = 0, Wh = 0, Wp = 0, batch = 0, dtype = 0;
+    int H = 0, W = 0, Wh = 0, batch = 0, dtype = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     FftDesc fw{}, fh{}, fa{}, fb{};
     int A = 1, B = 1;          // column transform split H = A x B (A = 1: one pass)
-    int cshift_res2 = 0, cshift_mul = 0, cshift_split = 0;
-    int col_threads = 256;
+    int cs = 0, ntile = 1;     // spectral arrays are stored in tiles of C = 1 << cs columns
+    size_t spec_plane = 0;     // complex elements of one image's half-spectrum (ntile * H * C)
+    int col_threads = 0;
     int row_threads = 0;       // 0 = heuristic
+    int row_wg_per_cu = 2;
     int tune_cols = 0, tune_A = 0;
     int num_cu = 256;
     // device buffers (typed by dtype)
@@ -171,6 +164,7 @@ struct ddn_plan {
     double* partials = nullptr;  // [batch*H][4]
     int* stop = nullptr;         // [batch]
     bool have_K = false, have_G = false, injected = false;
+    long long* dbg = nullptr;    // diagnostic phase stamps (DDN_DEBUG_STAMPS=1), 16 per workgroup
     // timing
     bool timing = false;
     std::vector<EvPair> ev_row, ev_col;
@@ -182,15 +176,24 @@ namespace {
 
 template <typename T>
 size_t col_lds_bytes(int n, int cshift, int narr) {
-    return (size_t)narr * lds_round(n << cshift) * sizeof(cx<T>) + (size_t)n * sizeof(cx<T>) + 16 * 4 * sizeof(double);
+    return (size_t)narr * lds_round(n << cshift) * sizeof(cx<T>) + (size_t)tw_lds_entries(n) * sizeof(cx<T>) + 16 * 4 * sizeof(double);
 }
 
-// choose the column tiling; returns false if nothing fits
+SpecLayout layout_of(const ddn_plan* p) {
+    SpecLayout l;
+    l.H = p->H;
+    l.cs = p->cs;
+    l.ntile = p->ntile;
+    return l;
+}
+
+// Choose the column tiling: tile width C (also the storage tile of every spectral array) and, when
+// a whole column of C-wide tiles does not fit LDS, the split H = A x B.  Returns false if nothing fits.
 template <typename T>
 bool choose_col(ddn_plan* p) {
     const int H = p->H;
-    const int want = (sizeof(T) == 4) ? 16 : 8;     // columns for a 128-byte run
-    const int minc = (sizeof(T) == 4) ? 8 : 4;      // 64-byte run: still acceptable for one pass
+    const int want = (sizeof(T) == 4) ? 16 : 8;     // columns for a 128-byte piece
+    const int minc = (sizeof(T) == 4) ? 8 : 4;      // 64-byte piece: still acceptable for one pass
     auto fit = [&](int n, int narr) {
         int cs = -1;
         for (int c = 0; (1 << c) <= 32; ++c) {
@@ -205,7 +208,7 @@ bool choose_col(ddn_plan* p) {
     } else {
         int cs = fit(H, 2);
         if (cs < 0 || (1 << cs) < minc) {
-            // split H = A x B, A the largest factor <= sqrt(H) that keeps both factors transformable
+            // split H = A x B, A the largest factor <= sqrt(H)
             A = 1;
             for (int a = 2; (long)a * a <= (long)H; ++a) {
                 if (H % a == 0) A = a;
@@ -216,39 +219,34 @@ bool choose_col(ddn_plan* p) {
     p->A = A;
     p->B = H / A;
     if (!factorize(p->A, p->fa) || !factorize(p->B, p->fb)) return false;
-    int c2 = fit(p->B, 2), c1 = fit(p->B, 1);
-    if (c2 < 0 || c1 < 0) return false;
+    int c2 = fit(p->B, 2);
+    if (A > 1) c2 = std::min(c2, fit(p->A, 2));
+    if (c2 < 0) return false;
     int lim = 0;
     while ((1 << lim) < want) ++lim;
     if (p->tune_cols > 0) {
         lim = 0;
         while ((1 << lim) < p->tune_cols) ++lim;
     }
-    p->cshift_res2 = std::min(c2, lim);
-    p->cshift_mul = std::min(c1, lim);
-    if (A > 1) {
-        const int cA = fit(p->A, 1);
-        if (cA < 0) return false;
-        p->cshift_split = std::min(cA, (sizeof(T) == 4) ? 5 : 4);
-    }
+    p->cs = std::min(c2, lim);
+    p->ntile = (p->Wh + (1 << p->cs) - 1) >> p->cs;
+    p->spec_plane = ((size_t)p->ntile * p->H) << p->cs;
     return true;
 }
 
 template <typename T>
-int plan_alloc(ddn_plan* p) {
-    const size_t spec = (size_t)p->batch * p->H * p->Wp * sizeof(cx<T>);
-    int rc;
-    if ((rc = make_table<T>(p->W, (cx<T>**)&p->twW))) return rc;
-    if ((rc = make_table<T>(p->H, (cx<T>**)&p->twH))) return rc;
-    if (p->A > 1) {
-        if ((rc = make_table<T>(p->A, (cx<T>**)&p->twA))) return rc;
-        if ((rc = make_table<T>(p->B, (cx<T>**)&p->twB))) return rc;
+int alloc_spec(ddn_plan* p) {
+    void** bufs[] = {&p->S0, &p->S1, &p->eK, &p->G, &p->Gc, &p->tmp_mult};
+    for (void** q : bufs) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
     }
+    const size_t spec = (size_t)p->batch * p->spec_plane * sizeof(cx<T>);
     HIPCHK(hipMalloc(&p->S0, spec));
     HIPCHK(hipMalloc(&p->S1, spec));
     HIPCHK(hipMemset(p->S0, 0, spec));
     HIPCHK(hipMemset(p->S1, 0, spec));
-    const size_t m = (size_t)p->H * p->Wp;
+    const size_t m = p->spec_plane;
     HIPCHK(hipMalloc(&p->eK, m * sizeof(cx<T>)));
     HIPCHK(hipMalloc(&p->G, m * sizeof(T)));
     HIPCHK(hipMalloc(&p->Gc, m * sizeof(cx<T>)));
@@ -257,13 +255,41 @@ int plan_alloc(ddn_plan* p) {
     HIPCHK(hipMemset(p->G, 0, m * sizeof(T)));
     HIPCHK(hipMemset(p->Gc, 0, m * sizeof(cx<T>)));
     HIPCHK(hipMemset(p->tmp_mult, 0, m * sizeof(cx<T>)));
-    HIPCHK(hipMalloc(&p->eDrow, (size_t)p->Wp * sizeof(cx<T>)));
-    HIPCHK(hipMalloc(&p->ed2, (size_t)p->Wp * sizeof(T)));
-    std::vector<T> ed2(p->Wp, (T)0);
+    return DDN_OK;
+}
+
+template <typename T>
+int alloc_col_tables(ddn_plan* p) {
+    if (p->twA) (void)hipFree(p->twA);
+    if (p->twB) (void)hipFree(p->twB);
+    p->twA = p->twB = nullptr;
+    if (p->A > 1) {
+        int rc;
+        if ((rc = make_table<T>(p->A, (cx<T>**)&p->twA))) return rc;
+        if ((rc = make_table<T>(p->B, (cx<T>**)&p->twB))) return rc;
+    }
+    return DDN_OK;
+}
+
+template <typename T>
+int plan_alloc(ddn_plan* p) {
+    int rc;
+    if ((rc = make_table<T>(p->W, (cx<T>**)&p->twW))) return rc;
+    if ((rc = make_table<T>(p->H, (cx<T>**)&p->twH))) return rc;
+    if ((rc = alloc_col_tables<T>(p))) return rc;
+    if ((rc = alloc_spec<T>(p))) return rc;
+    const int Wt = p->Wh + 64;
+    HIPCHK(hipMalloc(&p->eDrow, (size_t)Wt * sizeof(cx<T>)));
+    HIPCHK(hipMalloc(&p->ed2, (size_t)Wt * sizeof(T)));
+    std::vector<T> ed2(Wt, (T)0);
     for (int k = 0; k < p->Wh; ++k) ed2[k] = (T)(2.0L - 2.0L * cosl(2.0L * 3.14159265358979323846264338327950288L * k / p->W));
-    HIPCHK(hipMemcpy(p->ed2, ed2.data(), (size_t)p->Wp * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->ed2, ed2.data(), (size_t)Wt * sizeof(T), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&p->partials, (size_t)p->batch * p->H * 4 * sizeof(double)));
     HIPCHK(hipMemset(p->partials, 0, (size_t)p->batch * p->H * 4 * sizeof(double)));
+    if (getenv("DDN_DEBUG_STAMPS")) {
+        HIPCHK(hipMalloc((void**)&p->dbg, 4096 * 16 * sizeof(long long)));
+        HIPCHK(hipMemset(p->dbg, 0, 4096 * 16 * sizeof(long long)));
+    }
     HIPCHK(hipMalloc((void**)&p->stop, (size_t)p->batch * sizeof(int)));
     HIPCHK(hipMemset(p->stop, 0xff, (size_t)p->batch * sizeof(int)));
     return DDN_OK;
@@ -322,6 +348,12 @@ int launch_col_one(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t 
     return DDN_OK;
 }
 
+inline int col_threads_for(const ddn_plan* p, int n, int cs, int narr) {
+    int threads = std::min(1024, std::max(64, (((n << cs) * narr) / 16 + 63) / 64 * 64));
+    if (p->col_threads > 0) threads = std::max(64, std::min(1024, p->col_threads / 64 * 64));
+    return threads;
+}
+
 // One full column stage (forward, pointwise algebra, inverse) in place on S0 (and S1).
 // MODE as in ddn_kernels.hpp; nplanes = images to process.
 template <typename T, int MODE>
@@ -335,96 +367,78 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
     a.greal = greal;
     a.gcplx = gcplx;
     a.twH = (const cx<T>*)p->twH;
-    a.H = p->H; a.Wh = p->Wh; a.Wp = p->Wp; a.batch = nplanes;
+    a.lay = layout_of(p);
+    a.batch = nplanes;
     a.conj_mult = conj_mult;
     a.scale = scale;
     a.lf = no_loss();
+    const int cs = p->cs;
     if (p->A == 1) {
         a.fd = p->fb;
         a.tw = (const cx<T>*)p->twH;
-        a.cshift = (NARR == 2) ? p->cshift_res2 : p->cshift_mul;
-        a.ntile = (p->Wh + (1 << a.cshift) - 1) >> a.cshift;
         a.nseg = 1; a.row_stride = 1; a.seg_stride = 0;
         a.outer = 0;
         a.lf = lf;
-        const size_t lds = col_lds_bytes<T>(a.fd.n, a.cshift, NARR);
-        int threads = std::min(512, std::max(64, ((a.fd.n << a.cshift) / 8 + 63) / 64 * 64));
-        if (p->col_threads > 0) threads = std::min(threads, std::max(p->col_threads, 64));
-        return launch_col_one<T, MODE>(p, a, nplanes * a.ntile, threads, lds);
+        return launch_col_one<T, MODE>(p, a, nplanes * a.lay.ntile, col_threads_for(p, a.fd.n, cs, NARR), col_lds_bytes<T>(a.fd.n, cs, NARR));
     }
     // split transform: strided length-A stage, middle length-B stage (with the pointwise algebra),
     // strided length-A inverse stage
     ColArgs<T> s = a;
     s.fd = p->fa;
     s.tw = (const cx<T>*)p->twA;
-    s.cshift = p->cshift_split;
-    s.ntile = (p->Wh + (1 << s.cshift) - 1) >> s.cshift;
     s.nseg = p->B; s.row_stride = p->B; s.seg_stride = 1;
     s.outer = 0;
     s.scale = (T)1;
-    const size_t lds_s = col_lds_bytes<T>(p->A, s.cshift, NARR);
-    const int thr_s = std::min(512, std::max(64, ((p->A << s.cshift) * NARR / 8 + 63) / 64 * 64));
+    const int thr_s = col_threads_for(p, p->A, cs, NARR);
+    const size_t lds_s = col_lds_bytes<T>(p->A, cs, NARR);
+    const int nb_s = nplanes * s.nseg * s.lay.ntile;
     int rc;
-    // forward short stage: run as COL_FWD on each array (S0 and, for RES2, S1)
     s.dir = 0;
     s.lf = lf;  // the loss of the previous iteration is finalised by the first launch
-    if ((rc = launch_col_one<T, COL_FWD>(p, s, nplanes * s.nseg * s.ntile, thr_s, col_lds_bytes<T>(p->A, s.cshift, 1)))) return rc;
+    if (NARR == 2) rc = launch_col_one<T, COL_FWD2>(p, s, nb_s, thr_s, lds_s);
+    else rc = launch_col_one<T, COL_FWD>(p, s, nb_s, thr_s, lds_s);
+    if (rc) return rc;
     s.lf = no_loss();
     s.lf.stop = lf.stop; s.lf.iter = lf.iter;
-    if (NARR == 2) {
-        std::swap(s.S0, s.S1);
-        if ((rc = launch_col_one<T, COL_FWD>(p, s, nplanes * s.nseg * s.ntile, thr_s, col_lds_bytes<T>(p->A, s.cshift, 1)))) return rc;
-        std::swap(s.S0, s.S1);
-    }
-    (void)lds_s;
     // middle stage
     a.fd = p->fb;
     a.fa = p->fa;
     a.tw = (const cx<T>*)p->twB;
-    a.cshift = (NARR == 2) ? p->cshift_res2 : p->cshift_mul;
-    a.ntile = (p->Wh + (1 << a.cshift) - 1) >> a.cshift;
     a.nseg = p->A; a.row_stride = 1; a.seg_stride = p->B;
     a.outer = (MODE == COL_FWD) ? 1 : 3;
     a.lf.stop = lf.stop; a.lf.iter = lf.iter;
-    {
-        const size_t lds = col_lds_bytes<T>(a.fd.n, a.cshift, NARR);
-        int threads = std::min(512, std::max(64, ((a.fd.n << a.cshift) / 8 + 63) / 64 * 64));
-        if ((rc = launch_col_one<T, MODE>(p, a, nplanes * a.nseg * a.ntile, threads, lds))) return rc;
-    }
+    if ((rc = launch_col_one<T, MODE>(p, a, nplanes * a.nseg * a.lay.ntile, col_threads_for(p, a.fd.n, cs, NARR), col_lds_bytes<T>(a.fd.n, cs, NARR)))) return rc;
     if (MODE == COL_FWD) return DDN_OK;
     // inverse short stage
     s.dir = 1;
-    if ((rc = launch_col_one<T, COL_FWD>(p, s, nplanes * s.nseg * s.ntile, thr_s, col_lds_bytes<T>(p->A, s.cshift, 1)))) return rc;
-    if (NARR == 2) {
-        std::swap(s.S0, s.S1);
-        if ((rc = launch_col_one<T, COL_FWD>(p, s, nplanes * s.nseg * s.ntile, thr_s, col_lds_bytes<T>(p->A, s.cshift, 1)))) return rc;
-    }
-    return DDN_OK;
+    if (NARR == 2) rc = launch_col_one<T, COL_FWD2>(p, s, nb_s, thr_s, lds_s);
+    else rc = launch_col_one<T, COL_FWD>(p, s, nb_s, thr_s, lds_s);
+    return rc;
 }
 
 struct RowCfg {
-    int V, NG, threads, grid;
+    int V, threads, grid;
     size_t lds;
 };
 
+// Row workgroup shape: V = 4 pixels per lane-access (16 B) and four groups per thread when the
+// arrays are 16-byte aligned and W <= 4096; otherwise scalar accesses, eight pixels per thread.
 template <typename T>
 bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc) {
     const int W = p->W;
     if (aligned && W % 4 == 0 && W <= 4096) {
         rc.V = 4;
-        rc.NG = 4;
         rc.threads = std::min(256, std::max(64, (W / 16 + 63) / 64 * 64));
     } else {
         if (W > 8192) return false;
         rc.V = 1;
-        rc.NG = 8;
         rc.threads = std::min(1024, std::max(64, ((W + 7) / 8 + 63) / 64 * 64));
     }
-    if (p->row_threads > 0 && rc.V == 4) rc.threads = std::min(256, std::max(rc.threads, p->row_threads));
     rc.lds = row_lds_bytes<T>(W, rc.V);
     if (rc.lds > kLdsMax) return false;
     int per_cu = (int)std::min<size_t>(8, kLdsMax / rc.lds);
     per_cu = std::max(1, std::min(per_cu, 2048 / rc.threads));
+    if (rc.V == 4) per_cu = std::min(per_cu, p->row_wg_per_cu);   // the V = 4 kernels are compiled for 2 workgroups of 256 per CU
     rc.grid = std::max(1, std::min(work_items, p->num_cu * per_cu));
     return true;
 }
@@ -433,9 +447,10 @@ template <typename T>
 RowCommon<T> row_common(ddn_plan* p, int V, bool consume, bool produce) {
     RowCommon<T> c;
     std::memset(&c, 0, sizeof(c));
-    c.H = p->H; c.W = p->W; c.Wp = p->Wp; c.batch = p->batch;
+    c.H = p->H; c.W = p->W; c.batch = p->batch;
     c.V_groups = p->W / V;
     c.fw = p->fw;
+    c.lay = layout_of(p);
     c.twW = (const cx<T>*)p->twW;
     c.S0 = (cx<T>*)p->S0;
     c.S1 = (cx<T>*)p->S1;
@@ -444,26 +459,26 @@ RowCommon<T> row_common(ddn_plan* p, int V, bool consume, bool produce) {
     c.partials = p->partials;
     c.do_consume = consume ? 1 : 0;
     c.do_produce = produce ? 1 : 0;
+    c.dbg = p->dbg;
+    c.dbg_mode = getenv("DDN_DEBUG_MODE") ? atoi(getenv("DDN_DEBUG_MODE")) : 0;
     return c;
 }
 
 inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
-#define LAUNCH_ROW(KERN, ARGS, CFG)                                                                          \
-    do {                                                                                                     \
-        int rc_;                                                                                             \
-        TimerScope ts_(p, true);                                                                             \
-        if ((CFG).V == 4) {                                                                                  \
-            auto fn_ = KERN<T, 4, 4, 256>;                                                                   \
-            if ((rc_ = ensure_lds_attr((const void*)fn_))) return rc_;                                       \
-            hipLaunchKernelGGL(fn_, dim3((CFG).grid), dim3((CFG).threads), (CFG).lds, p->stream, ARGS);      \
-        } else {                                                                                             \
-            auto fn_ = KERN<T, 1, 8, 1024>;                                                                  \
-            if ((rc_ = ensure_lds_attr((const void*)fn_))) return rc_;                                       \
-            hipLaunchKernelGGL(fn_, dim3((CFG).grid), dim3((CFG).threads), (CFG).lds, p->stream, ARGS);      \
-        }                                                                                                    \
-        HIPCHK(hipGetLastError());                                                                           \
-    } while (0)
+// fused solver row kernels live in their own translation units (ddn_row_*.hip), one per policy
+// and dtype, so that they compile in parallel; see ddn_launch.hpp.
+template <typename T, class P>
+int launch_solver_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, const typename P::Args& a) {
+    TimerScope ts(p, true);
+    return row_launch<T, P>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.V, c, a);
+}
+
+template <typename T>
+int launch_cp_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, const CpArgs<T>& a) {
+    TimerScope ts(p, true);
+    return cp_launch<T>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.V, c, a);
+}
 
 template <typename T>
 int launch_finalize(ddn_plan* p, const LossFin& lf) {
@@ -507,8 +522,8 @@ template <typename T>
 int rows_r2c(ddn_plan* p, const T* src, int nplanes) {
     PlainRowArgs<T> a;
     std::memset(&a, 0, sizeof(a));
-    a.H = p->H; a.W = p->W; a.Wp = p->Wp; a.batch = nplanes;
-    a.fw = p->fw; a.twW = (const cx<T>*)p->twW; a.S = (cx<T>*)p->S0; a.src = src;
+    a.H = p->H; a.W = p->W; a.batch = nplanes;
+    a.fw = p->fw; a.lay = layout_of(p); a.twW = (const cx<T>*)p->twW; a.S = (cx<T>*)p->S0; a.src = src;
     const size_t lds = row_lds_bytes<T>(p->W, 1);
     if (lds > kLdsMax) return fail(DDN_E_UNSUPPORTED, "row length too large for LDS");
     auto fn = k_rows_r2c<T>;
@@ -524,8 +539,9 @@ template <typename T>
 int rows_c2r(ddn_plan* p, T* dst, int nplanes, T scale, const T* add) {
     PlainRowArgs<T> a;
     std::memset(&a, 0, sizeof(a));
-    a.H = p->H; a.W = p->W; a.Wp = p->Wp; a.batch = nplanes;
-    a.fw = p->fw; a.twW = (const cx<T>*)p->twW; a.S = (cx<T>*)p->S0; a.dst = dst; a.scale = scale; a.add = add;
+    a.H = p->H; a.W = p->W; a.batch = nplanes;
+    a.fw = p->fw; a.lay = layout_of(p); a.twW = (const cx<T>*)p->twW; a.S = (cx<T>*)p->S0; a.dst = dst; a.scale = scale;
+    (void)add;
     const size_t lds = row_lds_bytes<T>(p->W, 1);
     auto fn = k_rows_c2r<T>;
     int rc;
@@ -554,10 +570,10 @@ int import_full(ddn_plan* p, const void* full, int cdtype, int recip, int conj_i
     const size_t total = (size_t)p->H * p->Wh;
     if (cdtype == DDN_C64)
         hipLaunchKernelGGL((k_import_mult<T, float>), dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<float>*)full, out, out_real,
-                           p->H, p->W, p->Wh, p->Wp, colmap<T>(p), recip, conj_in, scale);
+                           p->H, p->W, p->Wh, layout_of(p), colmap<T>(p), recip, conj_in, scale);
     else
         hipLaunchKernelGGL((k_import_mult<T, double>), dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<double>*)full, out, out_real,
-                           p->H, p->W, p->Wh, p->Wp, colmap<T>(p), recip, conj_in, scale);
+                           p->H, p->W, p->Wh, layout_of(p), colmap<T>(p), recip, conj_in, scale);
     HIPCHK(hipGetLastError());
     return DDN_OK;
 }
@@ -591,7 +607,7 @@ int set_kernel_impl(ddn_plan* p, const double* taps, int kh, int kw, bool as_con
     int rc = rows_r2c<T>(p, dimg, 1);
     if (!rc) rc = col_stage<T, COL_FWD>(p, 1, nullptr, nullptr, nullptr, 0, (T)1, no_loss());
     if (!rc) {
-        hipError_t e = hipMemcpyAsync(out, p->S0, sizeof(cx<T>) * (size_t)H * p->Wp, hipMemcpyDeviceToDevice, p->stream);
+        hipError_t e = hipMemcpyAsync(out, p->S0, sizeof(cx<T>) * p->spec_plane, hipMemcpyDeviceToDevice, p->stream);
         if (e != hipSuccess) rc = fail(DDN_E_HIP, hipGetErrorString(e));
     }
     (void)hipStreamSynchronize(p->stream);
@@ -611,7 +627,7 @@ int set_resolvent_impl(ddn_plan* p, double cK, double cD, const void* M_dev, int
     if (!p->have_K) return fail(DDN_E_STATE, "set_resolvent: no blur kernel set");
     const size_t total = (size_t)p->H * p->Wh;
     hipLaunchKernelGGL(k_make_G<T>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<T>*)p->eK, (const T*)p->ed2, (T*)p->G,
-                       p->H, p->Wh, p->Wp, (T)cK, (T)cD, (T)scale);
+                       p->H, p->Wh, layout_of(p), (T)cK, (T)cD, (T)scale);
     HIPCHK(hipGetLastError());
     p->have_G = true;
     return DDN_OK;
@@ -626,7 +642,8 @@ int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, doubl
     RowCfg cfg;
     const bool al = aligned16(z1) && aligned16(z2) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
-    PdrArgs<T> a;
+    typename PdrP<T>::Args a;
+    RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
     a.z1 = (T*)z1; a.z20 = (T*)z2; a.z21 = (T*)z2 + plane; a.z22 = (T*)z2 + 2 * plane; a.b = (const T*)b;
     a.t = (T)t; a.rho = (T)rho; a.tg = (T)(t * gamma); a.l2div = (T)(2 * t + 1); a.objective = objective;
@@ -634,13 +651,13 @@ int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, doubl
     if ((rc = reset_stop<T>(p))) return rc;
     const cx<T>* gc = p->injected ? (const cx<T>*)p->Gc : nullptr;
     if (n_iters > 0) {
-        a.c = row_common<T>(p, cfg.V, false, true);
-        LAUNCH_ROW(k_pdr_row, a, cfg);
+        rc0 = row_common<T>(p, cfg.V, false, true);
+        if ((rc = launch_solver_row<T, PdrP<T>>(p, cfg, rc0, a))) return rc;
         for (int c = 1; c <= n_iters; ++c) {
             LossFin lf = make_lf(p, ring, c - 1, tol_kind, tol, first_loss_iter, true);
             if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
-            a.c = row_common<T>(p, cfg.V, true, c < n_iters);
-            LAUNCH_ROW(k_pdr_row, a, cfg);
+            rc0 = row_common<T>(p, cfg.V, true, c < n_iters);
+            if ((rc = launch_solver_row<T, PdrP<T>>(p, cfg, rc0, a))) return rc;
         }
         if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, tol_kind, tol, first_loss_iter, true)))) return rc;
     }
@@ -655,7 +672,8 @@ int pddr_run_impl(ddn_plan* p, void* pp, void* q, const void* b, double t, doubl
     RowCfg cfg;
     const bool al = aligned16(pp) && aligned16(q) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
-    PddrArgs<T> a;
+    typename PddrP<T>::Args a;
+    RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
     a.p = (T*)pp; a.q0 = (T*)q; a.q1 = (T*)q + plane; a.q2 = (T*)q + 2 * plane; a.b = (const T*)b;
     a.t = (T)t; a.it = (T)(1.0 / t); a.rho = (T)rho; a.itg = (T)((1.0 / t) * gamma);
@@ -663,13 +681,13 @@ int pddr_run_impl(ddn_plan* p, void* pp, void* q, const void* b, double t, doubl
     if ((rc = reset_stop<T>(p))) return rc;
     const cx<T>* gc = p->injected ? (const cx<T>*)p->Gc : nullptr;
     if (n_iters > 0) {
-        a.c = row_common<T>(p, cfg.V, false, true);
-        LAUNCH_ROW(k_pddr_row, a, cfg);
+        rc0 = row_common<T>(p, cfg.V, false, true);
+        if ((rc = launch_solver_row<T, PddrP<T>>(p, cfg, rc0, a))) return rc;
         for (int c = 1; c <= n_iters; ++c) {
             LossFin lf = make_lf(p, ring, c - 1, tol_kind, tol, first_loss_iter, true);
             if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
-            a.c = row_common<T>(p, cfg.V, true, c < n_iters);
-            LAUNCH_ROW(k_pddr_row, a, cfg);
+            rc0 = row_common<T>(p, cfg.V, true, c < n_iters);
+            if ((rc = launch_solver_row<T, PddrP<T>>(p, cfg, rc0, a))) return rc;
         }
         if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, tol_kind, tol, first_loss_iter, true)))) return rc;
     }
@@ -685,7 +703,8 @@ int admm_run_impl(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b
     RowCfg cfg;
     const bool al = aligned16(u) && aligned16(w) && aligned16(y) && aligned16(z) && aligned16(b) && aligned16(sol) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
-    AdmmArgs<T> a;
+    typename AdmmP<T>::Args a;
+    RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
     a.u = (T*)u; a.w = (T*)w;
     a.y0 = (T*)y; a.y1 = (T*)y + plane; a.y2 = (T*)y + 2 * plane;
@@ -697,23 +716,23 @@ int admm_run_impl(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b
     if ((rc = reset_stop<T>(p))) return rc;
     const cx<T>* gc = p->injected ? (const cx<T>*)p->Gc : nullptr;
     // produce the transform inputs of the first solve
-    a.c = row_common<T>(p, cfg.V, false, true);
+    rc0 = row_common<T>(p, cfg.V, false, true);
     a.sol = nullptr; a.sol_only = 0;
-    LAUNCH_ROW(k_admm_row, a, cfg);
+    if ((rc = launch_solver_row<T, AdmmP<T>>(p, cfg, rc0, a))) return rc;
     for (int c = 1; c <= n_iters; ++c) {
         // partial sums written by call c-1 describe sol of iteration c-2
         LossFin lf = make_lf(p, ring, c - 2, tol_kind, tol, first_loss_iter, true);
         if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
-        a.c = row_common<T>(p, cfg.V, true, true);
+        rc0 = row_common<T>(p, cfg.V, true, true);
         a.sol = (tol_kind > 0) ? (T*)sol : nullptr;
-        LAUNCH_ROW(k_admm_row, a, cfg);
+        if ((rc = launch_solver_row<T, AdmmP<T>>(p, cfg, rc0, a))) return rc;
     }
     {
         LossFin lf = make_lf(p, ring, n_iters - 1, tol_kind, tol, first_loss_iter, true);
         if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
-        a.c = row_common<T>(p, cfg.V, true, false);
+        rc0 = row_common<T>(p, cfg.V, true, false);
         a.sol = (T*)sol; a.sol_only = 1;
-        LAUNCH_ROW(k_admm_row, a, cfg);
+        if ((rc = launch_solver_row<T, AdmmP<T>>(p, cfg, rc0, a))) return rc;
         if (n_iters >= 1)
             if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, tol_kind, tol, first_loss_iter, true)))) return rc;
     }
@@ -728,6 +747,7 @@ int cp_run_impl(ddn_plan* p, void* x, void* z, void* y, const void* b, double t,
     const bool al = aligned16(x) && aligned16(z) && aligned16(y) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * ((p->H + 1) / 2), cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
     CpArgs<T> a;
+    RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
     a.x = (T*)x; a.z = (T*)z; a.y0 = (T*)y; a.y1 = (T*)y + plane; a.y2 = (T*)y + 2 * plane; a.b = (const T*)b;
     a.t = (T)t; a.s = (T)s; a.is = (T)(1.0 / s); a.isg = (T)((1.0 / s) * gamma); a.l2div = (T)(2 * (1.0 / s) + 1); a.objective = objective;
@@ -736,21 +756,21 @@ int cp_run_impl(ddn_plan* p, void* x, void* z, void* y, const void* b, double t,
     const T scale = (T)(1.0 / ((double)p->H * (double)p->W));
     if (n_iters > 0) {
         a.step = 1;
-        a.c = row_common<T>(p, cfg.V, false, true);
-        a.c.stop = nullptr;
-        LAUNCH_ROW(k_cp_row, a, cfg);
+        rc0 = row_common<T>(p, cfg.V, false, true);
+        rc0.stop = nullptr;
+        if ((rc = launch_cp_row<T>(p, cfg, rc0, a))) return rc;
         for (int c = 1; c <= n_iters; ++c) {
             LossFin lf = make_lf(p, ring, c - 1, 0, 0.0, 1, false);
             if ((rc = col_stage<T, COL_MUL>(p, p->batch, (const cx<T>*)p->eK, nullptr, nullptr, 0, scale, lf))) return rc;
             a.step = 0;
-            a.c = row_common<T>(p, cfg.V, true, true);
-            a.c.stop = nullptr;
-            LAUNCH_ROW(k_cp_row, a, cfg);
+            rc0 = row_common<T>(p, cfg.V, true, true);
+            rc0.stop = nullptr;
+            if ((rc = launch_cp_row<T>(p, cfg, rc0, a))) return rc;
             if ((rc = col_stage<T, COL_MUL>(p, p->batch, (const cx<T>*)p->eK, nullptr, nullptr, 1, scale, no_loss()))) return rc;
             a.step = 1;
-            a.c = row_common<T>(p, cfg.V, true, c < n_iters);
-            a.c.stop = nullptr;
-            LAUNCH_ROW(k_cp_row, a, cfg);
+            rc0 = row_common<T>(p, cfg.V, true, c < n_iters);
+            rc0.stop = nullptr;
+            if ((rc = launch_cp_row<T>(p, cfg, rc0, a))) return rc;
         }
         if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, 0, 0.0, 1, false)))) return rc;
     }
@@ -769,7 +789,7 @@ int apply_impl(ddn_plan* p, int op, const void* x, void* y) {
         case DDN_OP_D:
         case DDN_OP_DT:
             if (p->injected) {
-                hipLaunchKernelGGL(k_bcast_row<T>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<T>*)p->eDrow, (cx<T>*)p->tmp_mult, p->H, p->Wh, p->Wp);
+                hipLaunchKernelGGL(k_bcast_row<T>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<T>*)p->eDrow, (cx<T>*)p->tmp_mult, p->H, p->Wh, layout_of(p));
                 HIPCHK(hipGetLastError());
                 return apply_mult<T>(p, (const cx<T>*)p->tmp_mult, op == DDN_OP_DT, (const T*)x, (T*)y, p->batch);
             }
@@ -786,7 +806,7 @@ int apply_impl(ddn_plan* p, int op, const void* x, void* y) {
         }
         case DDN_OP_MAT: {
             if (!p->have_K) return fail(DDN_E_STATE, "apply: no blur kernel set");
-            hipLaunchKernelGGL(k_make_mat<T>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<T>*)p->eK, (const T*)p->ed2, (cx<T>*)p->tmp_mult, p->H, p->Wh, p->Wp);
+            hipLaunchKernelGGL(k_make_mat<T>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<T>*)p->eK, (const T*)p->ed2, (cx<T>*)p->tmp_mult, p->H, p->Wh, layout_of(p));
             HIPCHK(hipGetLastError());
             return apply_mult<T>(p, (const cx<T>*)p->tmp_mult, 0, (const T*)x, (T*)y, p->batch);
         }
@@ -800,7 +820,7 @@ int apply_impl(ddn_plan* p, int op, const void* x, void* y) {
 extern "C" {
 
 int ddn_version(void) { return 100; }
-const char* ddn_last_error(void) { return g_err.c_str(); }
+const char* ddn_last_error(void) { return ddn_err().c_str(); }
 
 int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* stream) {
     if (!out || H < 1 || W < 2 || batch < 1 || (dtype != DDN_F32 && dtype != DDN_F64)) return fail(DDN_E_ARG, "plan_create: bad arguments");
@@ -809,7 +829,6 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
     ddn_plan* p = new ddn_plan();
     p->H = H; p->W = W; p->batch = batch; p->dtype = dtype; p->stream = (hipStream_t)stream;
     p->Wh = W / 2 + 1;
-    p->Wp = (p->Wh + 31) / 32 * 32;
     (void)hipGetDevice(&p->device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->num_cu = prop.multiProcessorCount;
@@ -823,7 +842,7 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
         return fail(DDN_E_UNSUPPORTED, "plan_create: column transform does not fit LDS");
     }
     if (p->A == 1) p->fb = p->fh;
-    const size_t rl = dtype == DDN_F32 ? row_lds_bytes<float>(W, 1) : row_lds_bytes<double>(W, 1);
+    const size_t rl = dtype == DDN_F32 ? row_lds_bytes<float>(W, 4) : row_lds_bytes<double>(W, 4);
     if (rl > kLdsMax) {
         delete p;
         return fail(DDN_E_UNSUPPORTED, "plan_create: row length too large for LDS");
@@ -856,31 +875,23 @@ int ddn_plan_set_stream(ddn_plan* p, void* stream) {
     return DDN_OK;
 }
 
-int ddn_plan_tune(ddn_plan* p, int cols_per_block, int split_A, int row_threads) {
+int ddn_plan_tune(ddn_plan* p, int cols_per_block, int split_A, int col_threads) {
     if (!p) return fail(DDN_E_ARG, "null plan");
     if (p->have_K) return fail(DDN_E_STATE, "plan_tune must precede set_kernel / set_eig");
     if (split_A > 0 && p->H % split_A) return fail(DDN_E_ARG, "plan_tune: split_A does not divide H");
-    const int oldA = p->A;
     p->tune_cols = cols_per_block;
     p->tune_A = split_A;
-    p->row_threads = row_threads;
+    p->col_threads = col_threads;
     const bool ok = p->dtype == DDN_F32 ? choose_col<float>(p) : choose_col<double>(p);
     if (!ok) return fail(DDN_E_UNSUPPORTED, "plan_tune: tiling does not fit LDS");
     if (p->A == 1) p->fb = p->fh;
-    if (p->A != oldA && p->A > 1) {
-        if (p->twA) (void)hipFree(p->twA);
-        if (p->twB) (void)hipFree(p->twB);
-        p->twA = p->twB = nullptr;
-        int rc;
-        if (p->dtype == DDN_F32) {
-            if ((rc = make_table<float>(p->A, (cx<float>**)&p->twA))) return rc;
-            if ((rc = make_table<float>(p->B, (cx<float>**)&p->twB))) return rc;
-        } else {
-            if ((rc = make_table<double>(p->A, (cx<double>**)&p->twA))) return rc;
-            if ((rc = make_table<double>(p->B, (cx<double>**)&p->twB))) return rc;
-        }
+    int rc;
+    if (p->dtype == DDN_F32) {
+        if ((rc = alloc_col_tables<float>(p))) return rc;
+        return alloc_spec<float>(p);
     }
-    return DDN_OK;
+    if ((rc = alloc_col_tables<double>(p))) return rc;
+    return alloc_spec<double>(p);
 }
 
 int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
@@ -918,7 +929,7 @@ int ddn_plan_set_eig(ddn_plan* p, const void* eigK, const void* eigD, int cdtype
             row[2 * k + 1] = (double)(-sinl(ang));
         }
     }
-    std::vector<double> sym(2 * (size_t)p->Wp, 0.0), ed2(p->Wp, 0.0);
+    std::vector<double> sym(2 * (size_t)p->Wh, 0.0);
     for (int k = 0; k < Wh; ++k) {
         const int km = k == 0 ? 0 : W - k;
         sym[2 * k] = 0.5 * (row[2 * k] + row[2 * km]);
@@ -926,9 +937,9 @@ int ddn_plan_set_eig(ddn_plan* p, const void* eigK, const void* eigD, int cdtype
     }
     if (p->dtype == DDN_F32) {
         std::vector<float> f(sym.begin(), sym.end());
-        HIPCHK(hipMemcpy(p->eDrow, f.data(), sizeof(float) * 2 * p->Wp, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(p->eDrow, f.data(), sizeof(float) * 2 * p->Wh, hipMemcpyHostToDevice));
     } else {
-        HIPCHK(hipMemcpy(p->eDrow, sym.data(), sizeof(double) * 2 * p->Wp, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(p->eDrow, sym.data(), sizeof(double) * 2 * p->Wh, hipMemcpyHostToDevice));
     }
     p->injected = true;
     return DDN_OK;
@@ -945,9 +956,9 @@ int ddn_plan_get_eigK(ddn_plan* p, void* out_dev) {
     if (!p->have_K) return fail(DDN_E_STATE, "get_eigK: no blur kernel set");
     const size_t total = (size_t)p->H * p->W;
     if (p->dtype == DDN_F32)
-        hipLaunchKernelGGL(k_export_full<float>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<float>*)p->eK, (cx<float>*)out_dev, p->H, p->W, p->Wp, colmap<float>(p));
+        hipLaunchKernelGGL(k_export_full<float>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<float>*)p->eK, (cx<float>*)out_dev, p->H, p->W, layout_of(p), colmap<float>(p));
     else
-        hipLaunchKernelGGL(k_export_full<double>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<double>*)p->eK, (cx<double>*)out_dev, p->H, p->W, p->Wp, colmap<double>(p));
+        hipLaunchKernelGGL(k_export_full<double>, dim3(ew_grid(total)), dim3(256), 0, p->stream, (const cx<double>*)p->eK, (cx<double>*)out_dev, p->H, p->W, layout_of(p), colmap<double>(p));
     HIPCHK(hipGetLastError());
     return DDN_OK;
 }
@@ -1053,6 +1064,14 @@ int ddn_pddr_run(ddn_plan* p, void* pp, void* q, const void* b, double t, double
     p->ev_row.clear(); p->ev_col.clear(); p->ev_used = 0;
     return p->dtype == DDN_F32 ? pddr_run_impl<float>(p, pp, q, b, t, rho, gamma, n_iters, tol_kind, tol, first_loss_iter, ring, iters_done)
                                : pddr_run_impl<double>(p, pp, q, b, t, rho, gamma, n_iters, tol_kind, tol, first_loss_iter, ring, iters_done);
+}
+
+// diagnostic: copies the phase stamps of the last fused row kernel launch (16 int64 per workgroup)
+int ddn_plan_debug_stamps(ddn_plan* p, long long* out_host, int n_wg) {
+    if (!p || !p->dbg) return fail(DDN_E_STATE, "debug stamps are off (set DDN_DEBUG_STAMPS=1 before plan_create)");
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipMemcpy(out_host, p->dbg, sizeof(long long) * 16 * (size_t)std::min(n_wg, 4096), hipMemcpyDeviceToHost));
+    return DDN_OK;
 }
 
 int ddn_plan_enable_timing(ddn_plan* p, int on) {

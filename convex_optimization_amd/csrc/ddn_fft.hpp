@@ -57,6 +57,42 @@ struct FftDesc {
     int twmul[DDN_MAXPASS];
 };
 
+// Twiddle source exp(-2 pi i e / n), e in [0, n).  Short transforms keep the whole table in LDS; long
+// ones keep two small tables and form w^e = w^(64*(e>>6)) * w^(e&63) with one complex multiply, so
+// that the table does not compete with the data for LDS (a 4096-entry table would halve occupancy).
+#define DDN_TW_DIRECT_MAX 1024
+template <typename T>
+struct Tw {
+    const cx<T>* t1;
+    const cx<T>* t2;
+    int two;
+    __device__ __forceinline__ cx<T> operator[](int e) const {
+        if (!two) return t1[e];
+        return t1[e >> 6] * t2[e & 63];
+    }
+};
+__host__ __device__ __forceinline__ int tw_hi_entries(int n) { return ((n - 1) >> 6) + 1; }
+// entries of LDS needed for the twiddles of a length-n transform
+__host__ __device__ __forceinline__ int tw_lds_entries(int n) { return n <= DDN_TW_DIRECT_MAX ? n : tw_hi_entries(n) + 64; }
+// Global layout produced by the host: [direct n][hi tw_hi_entries(n)][lo 64].
+template <typename T>
+__device__ __forceinline__ Tw<T> tw_setup(cx<T>* area, const cx<T>* glob, int n, int tid, int nt) {
+    Tw<T> tw;
+    if (n <= DDN_TW_DIRECT_MAX) {
+        for (int i = tid; i < n; i += nt) area[i] = glob[i];
+        tw.t1 = area;
+        tw.t2 = area;
+        tw.two = 0;
+    } else {
+        const int nh = tw_hi_entries(n);
+        for (int i = tid; i < nh + 64; i += nt) area[i] = glob[n + i];
+        tw.t1 = area;
+        tw.t2 = area + nh;
+        tw.two = 1;
+    }
+    return tw;
+}
+
 // LDS index swizzle: XOR the low five index bits with two higher bit groups so that the strided
 // accesses of the butterfly passes (strides 16, 32, 256, 1024 ... elements) and the
 // digit-reversed gathers spread over the banks.  A bijection on every aligned block of 32.
@@ -206,7 +242,7 @@ struct Dft<T, 5, INV> {
 // Generic odd prime radix (7, 11, 13): direct O(R^2) evaluation with exact table twiddles.
 // tw is the length-n table exp(-2 pi i e / n) of the enclosing transform, n % R == 0.
 template <typename T, int R, bool INV>
-__device__ __forceinline__ void dft_prime(cx<T>* v, const cx<T>* tw, int n) {
+__device__ __forceinline__ void dft_prime(cx<T>* v, const Tw<T>& tw, int n) {
     cx<T> o[R];
     const int step = n / R;
 #pragma unroll
@@ -225,7 +261,7 @@ __device__ __forceinline__ void dft_prime(cx<T>* v, const cx<T>* tw, int n) {
 
 // One butterfly of pass s on column c: elements base + q*m, q = 0..R-1.
 template <typename T, int R, bool INV>
-__device__ __forceinline__ void butterfly(cx<T>* lds, const cx<T>* tw, int n, int base, int m, int jj, int twmul, int cshift, int c) {
+__device__ __forceinline__ void butterfly(cx<T>* lds, const Tw<T>& tw, int n, int base, int m, int jj, int twmul, int cshift, int c) {
     cx<T> v[R];
     int idx[R];
 #pragma unroll
@@ -257,7 +293,7 @@ __device__ __forceinline__ void butterfly(cx<T>* lds, const cx<T>* tw, int n, in
 
 // One full pass over `narr` arrays of n * C elements each (array a starts at lds + a*arr_stride).
 template <typename T, bool INV>
-__device__ __forceinline__ void fft_pass(cx<T>* lds, int narr, int arr_stride, const cx<T>* tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
+__device__ __forceinline__ void fft_pass(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
     const int r = d.radix[s], m = d.m[s], ms = d.mshift[s], twmul = d.twmul[s];
     const int per = (d.n / r) << cshift;
     const int total = per * narr;
@@ -296,7 +332,7 @@ __device__ __forceinline__ void fft_pass(cx<T>* lds, int narr, int arr_stride, c
 // Forward: natural -> digit-reversed.  Caller guarantees the input is visible (barrier before).
 // Ends with a barrier.
 template <typename T>
-__device__ __forceinline__ void fft_forward(cx<T>* lds, int narr, int arr_stride, const cx<T>* tw, const FftDesc& d, int cshift, int tid, int nt) {
+__device__ __forceinline__ void fft_forward(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int cshift, int tid, int nt) {
     for (int s = 0; s < d.npass; ++s) {
         fft_pass<T, false>(lds, narr, arr_stride, tw, d, s, cshift, tid, nt);
         __syncthreads();
@@ -304,9 +340,99 @@ __device__ __forceinline__ void fft_forward(cx<T>* lds, int narr, int arr_stride
 }
 // Inverse (unnormalised): digit-reversed -> natural.  Ends with a barrier.
 template <typename T>
-__device__ __forceinline__ void fft_inverse(cx<T>* lds, int narr, int arr_stride, const cx<T>* tw, const FftDesc& d, int cshift, int tid, int nt) {
+__device__ __forceinline__ void fft_inverse(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int cshift, int tid, int nt) {
     for (int s = d.npass - 1; s >= 0; --s) {
         fft_pass<T, true>(lds, narr, arr_stride, tw, d, s, cshift, tid, nt);
         __syncthreads();
     }
+}
+
+// ======================================================================================
+// Compile-time specialised transforms for power-of-two lengths.  Same radix schedule as the
+// host's factorize() (so positions agree with the generic code and with stored multipliers), but
+// every radix, stride and shift is a constant: straight-line code, a fraction of the generic
+// kernels' instruction footprint (which overflows the instruction cache).
+// ======================================================================================
+constexpr int ilog2_c(int n) { return n <= 1 ? 0 : 1 + ilog2_c(n >> 1); }
+constexpr int fixed_npass(int n) {
+    const int t = ilog2_c(n), a = t / 4, r = t % 4;
+    return t == 0 ? 0 : (r == 0 ? a : (r == 3 ? a + 1 : (a >= 1 ? a + 1 : 1)));
+}
+constexpr int fixed_radix(int n, int s) {
+    const int t = ilog2_c(n), a = t / 4, r = t % 4;
+    if (r == 0) return 16;
+    if (r == 3) return s < a ? 16 : 8;
+    if (r == 2) return a >= 1 ? (s < a - 1 ? 16 : 8) : 4;
+    return a >= 1 ? (s < a - 1 ? 16 : (s == a - 1 ? 8 : 4)) : 2;
+}
+constexpr int fixed_m(int n, int s) {  // n / (radix[0] * ... * radix[s])
+    int m = n;
+    for (int i = 0; i <= s; ++i) m /= fixed_radix(n, i);
+    return m;
+}
+
+template <int N>
+__device__ __forceinline__ int pos_of_freq_fixed(int k) {
+    int pos = 0;
+#pragma unroll
+    for (int s = 0; s < fixed_npass(N); ++s) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int r = fixed_radix(N, s);
+        pos += (k & (r - 1)) * fixed_m(N, s);
+        k /= r;
+    }
+    return pos;
+}
+
+template <typename T, int N, int S, bool INV>
+__device__ __forceinline__ void fixed_pass(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, int cshift, int tid, int nt) {
+    constexpr int R = fixed_radix(N, S), M = fixed_m(N, S), TWMUL = N / (M * R);
+    const int per = (N / R) << cshift;
+    const int total = per * narr;
+    for (int w = tid; w < total; w += nt) {
+        int a = 0, ww = w;
+        if (narr > 1) {
+            a = w / per;
+            ww = w - a * per;
+        }
+        const int c = ww & ((1 << cshift) - 1);
+        const int bf = ww >> cshift;
+        const int blk = bf / M, jj = bf % M;  // M is a power of two: shifts
+        butterfly<T, R, INV>(lds + a * arr_stride, tw, N, blk * (M * R) + jj, M, jj, TWMUL, cshift, c);
+    }
+}
+
+template <typename T, int N, int S = 0>
+__device__ __forceinline__ void fft_forward_fixed(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, int cshift, int tid, int nt) {
+    if constexpr (S < fixed_npass(N)) {
+        fixed_pass<T, N, S, false>(lds, narr, arr_stride, tw, cshift, tid, nt);
+        __syncthreads();
+        fft_forward_fixed<T, N, S + 1>(lds, narr, arr_stride, tw, cshift, tid, nt);
+    }
+}
+template <typename T, int N, int S = fixed_npass(N) - 1>
+__device__ __forceinline__ void fft_inverse_fixed(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, int cshift, int tid, int nt) {
+    if constexpr (S >= 0) {
+        fixed_pass<T, N, S, true>(lds, narr, arr_stride, tw, cshift, tid, nt);
+        __syncthreads();
+        fft_inverse_fixed<T, N, S - 1>(lds, narr, arr_stride, tw, cshift, tid, nt);
+    }
+}
+
+// Dispatchers: NF > 0 selects the specialised code, NF == 0 the generic run-time schedule.
+template <typename T, int NF>
+__device__ __forceinline__ void fft_fwd(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int cshift, int tid, int nt) {
+    if constexpr (NF > 0) fft_forward_fixed<T, NF>(lds, narr, arr_stride, tw, cshift, tid, nt);
+    else fft_forward<T>(lds, narr, arr_stride, tw, d, cshift, tid, nt);
+}
+template <typename T, int NF>
+__device__ __forceinline__ void fft_inv(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int cshift, int tid, int nt) {
+    if constexpr (NF > 0) fft_inverse_fixed<T, NF>(lds, narr, arr_stride, tw, cshift, tid, nt);
+    else fft_inverse<T>(lds, narr, arr_stride, tw, d, cshift, tid, nt);
+}
+template <int NF>
+__device__ __forceinline__ int pos_freq(const FftDesc& d, int k) {
+    if constexpr (NF > 0) return pos_of_freq_fixed<NF>(k);
+    else return pos_of_freq(d, k);
 }

@@ -87,65 +87,110 @@ __device__ __forceinline__ void block_reduce(double (&v)[NS], double* red, int t
     __syncthreads();
 }
 
-template <typename T>
-__device__ __forceinline__ void load_table(cx<T>* dst, const cx<T>* src, int n, int tid, int nt) {
-    for (int i = tid; i < n; i += nt) dst[i] = src[i];
+// ------------------------------------------------------------------ spectral array addressing
+// Half-row-spectra and multipliers are stored column-tile-major: tile t holds columns
+// [t*C, (t+1)*C) of every row contiguously, element (row, k2) of image `plane` at
+//   (((plane*ntile + (k2 >> cs)) * H + row) << cs) + (k2 & (C-1)),   C = 1 << cs.
+// A column workgroup therefore streams one contiguous H*C block; a row workgroup touches C-element
+// pieces, one per tile.
+struct SpecLayout {
+    int H, cs, ntile;
+};
+struct SpecRow {
+    size_t base;     // offset of (row, k2 = 0)
+    size_t tstride;  // H << cs
+    int cs;
+    __device__ __forceinline__ size_t at(int k2) const { return base + (size_t)(k2 >> cs) * tstride + (k2 & ((1 << cs) - 1)); }
+};
+__device__ __forceinline__ SpecRow spec_row(const SpecLayout& l, int plane, int row) {
+    SpecRow r;
+    r.base = ((size_t)plane * l.ntile * l.H + row) << l.cs;
+    r.tstride = (size_t)l.H << l.cs;
+    r.cs = l.cs;
+    return r;
 }
 
 // ------------------------------------------------------------------- row transform helpers
-// Pack the half-spectra of two real rows a, b (srcA, srcB; either may be null = zero) into the
-// full spectrum of a + i b, at digit-reversed LDS positions.  No barrier inside.
-template <typename T>
-__device__ __forceinline__ void row_pack(cx<T>* lds, const FftDesc& fw, int W, const cx<T>* srcA, const cx<T>* srcB, int tid, int nt,
-                                         const cx<T>* addA = nullptr, const cx<T>* addB = nullptr) {
+// Pack the half-spectra of two real rows a, b (either source may be null = zero; optional addends)
+// into the full spectrum of a + i b, at digit-reversed LDS positions.  No barrier inside.
+// All global loads of a thread are issued before the first use (KP = elements per thread, a
+// compile-time bound): the pack phase is otherwise a chain of dependent HBM round trips.
+template <typename T, int KP>
+__device__ __forceinline__ void row_pack_load(cx<T> (&U)[KP], cx<T> (&V)[KP], int W, const cx<T>* srcA, const SpecRow& ra, const cx<T>* srcB,
+                                              const SpecRow& rb, int tid, int nt, const cx<T>* addA = nullptr, const cx<T>* addB = nullptr) {
     const int half = W >> 1;
-    for (int k = tid; k <= half; k += nt) {
-        cx<T> U = srcA ? srcA[k] : mk<T>(0, 0);
-        cx<T> V = srcB ? srcB[k] : mk<T>(0, 0);
-        if (addA) U = U + addA[k];
-        if (addB) V = V + addB[k];
-        const int km = (k == 0) ? 0 : W - k;
-        if (km == k) {
-            lds[SW(pos_of_freq(fw, k))] = mk<T>(U.x, V.x);  // DC / Nyquist of a real row: imaginary part dropped
-        } else {
-            lds[SW(pos_of_freq(fw, k))] = mk<T>(U.x - V.y, U.y + V.x);
-            lds[SW(pos_of_freq(fw, km))] = mk<T>(U.x + V.y, V.x - U.y);
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int k = tid + i * nt;
+        U[i] = mk<T>(0, 0);
+        V[i] = mk<T>(0, 0);
+        if (k <= half) {
+            if (srcA) U[i] = srcA[ra.at(k)];
+            if (srcB) V[i] = srcB[rb.at(k)];
+            if (addA) U[i] = U[i] + addA[ra.at(k)];
+            if (addB) V[i] = V[i] + addB[rb.at(k)];
         }
     }
 }
+template <typename T, int KP, int NF = 0>
+__device__ __forceinline__ void row_pack_store(cx<T>* lds, const FftDesc& fw, int W, const cx<T> (&U)[KP], const cx<T> (&V)[KP], int tid, int nt) {
+    const int half = W >> 1;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int k = tid + i * nt;
+        if (k <= half) {
+            const int km = (k == 0) ? 0 : W - k;
+            if (km == k) {
+                lds[SW(pos_freq<NF>(fw, k))] = mk<T>(U[i].x, V[i].x);  // DC / Nyquist of a real row: imaginary part dropped
+            } else {
+                lds[SW(pos_freq<NF>(fw, k))] = mk<T>(U[i].x - V[i].y, U[i].y + V[i].x);
+                lds[SW(pos_freq<NF>(fw, km))] = mk<T>(U[i].x + V[i].y, V[i].x - U[i].y);
+            }
+        }
+    }
+}
+// KP * nt must cover W/2 + 1 entries (the callers' thread counts guarantee it).
+template <typename T, int KP, int NF = 0>
+__device__ __forceinline__ void row_pack(cx<T>* lds, const FftDesc& fw, int W, const cx<T>* srcA, const SpecRow& ra, const cx<T>* srcB,
+                                         const SpecRow& rb, int tid, int nt, const cx<T>* addA = nullptr, const cx<T>* addB = nullptr) {
+    cx<T> U[KP], V[KP];
+    row_pack_load<T, KP>(U, V, W, srcA, ra, srcB, rb, tid, nt, addA, addB);
+    row_pack_store<T, KP, NF>(lds, fw, W, U, V, tid, nt);
+}
 // As row_pack but a single source multiplied by a row table (row-spectral D: U[k] * eD[k]).
-template <typename T>
-__device__ __forceinline__ void row_pack_mul(cx<T>* lds, const FftDesc& fw, int W, const cx<T>* srcA, const cx<T>* rowmul, int tid, int nt) {
+template <typename T, int NF = 0>
+__device__ __forceinline__ void row_pack_mul(cx<T>* lds, const FftDesc& fw, int W, const cx<T>* srcA, const SpecRow& ra, const cx<T>* rowmul, int tid, int nt) {
     const int half = W >> 1;
     for (int k = tid; k <= half; k += nt) {
-        cx<T> U = srcA[k] * rowmul[k];
+        cx<T> U = srcA[ra.at(k)] * rowmul[k];
         const int km = (k == 0) ? 0 : W - k;
         if (km == k) {
-            lds[SW(pos_of_freq(fw, k))] = mk<T>(U.x, 0);
+            lds[SW(pos_freq<NF>(fw, k))] = mk<T>(U.x, 0);
         } else {
-            lds[SW(pos_of_freq(fw, k))] = U;
-            lds[SW(pos_of_freq(fw, km))] = cconj(U);
+            lds[SW(pos_freq<NF>(fw, k))] = U;
+            lds[SW(pos_freq<NF>(fw, km))] = cconj(U);
         }
     }
 }
 // LDS holds the digit-reversed spectrum Z of a + i b.  Separate A = F(a), B = F(b) for k2 = 0..W/2
-// and store them (null destination = skip).  mulA != null: dstA[k] (+)= conj(mulA[k]) * A instead
+// and store them (null destination = skip).  mulA != null: A is multiplied by conj(mulA[k]) first
 // (row-spectral D^T); accA adds to what dstA already holds.
-template <typename T>
-__device__ __forceinline__ void row_unpack(const cx<T>* lds, const FftDesc& fw, int W, cx<T>* dstA, cx<T>* dstB,
+template <typename T, int NF = 0>
+__device__ __forceinline__ void row_unpack(const cx<T>* lds, const FftDesc& fw, int W, cx<T>* dstA, const SpecRow& ra, cx<T>* dstB, const SpecRow& rb,
                                            const cx<T>* mulA, bool accA, int tid, int nt) {
     const int half = W >> 1;
     for (int k = tid; k <= half; k += nt) {
         const int km = (k == 0) ? 0 : W - k;
-        const cx<T> Z1 = lds[SW(pos_of_freq(fw, k))];
-        const cx<T> Z2 = lds[SW(pos_of_freq(fw, km))];
+        const cx<T> Z1 = lds[SW(pos_freq<NF>(fw, k))];
+        const cx<T> Z2 = lds[SW(pos_freq<NF>(fw, km))];
         if (dstA) {
             cx<T> A = mk<T>((T)0.5 * (Z1.x + Z2.x), (T)0.5 * (Z1.y - Z2.y));
             if (mulA) A = mulc(A, mulA[k]);
-            if (accA) A = A + dstA[k];
-            dstA[k] = A;
+            const size_t o = ra.at(k);
+            if (accA) A = A + dstA[o];
+            dstA[o] = A;
         }
-        if (dstB) dstB[k] = mk<T>((T)0.5 * (Z1.y + Z2.y), (T)0.5 * (Z2.x - Z1.x));
+        if (dstB) dstB[rb.at(k)] = mk<T>((T)0.5 * (Z1.y + Z2.y), (T)0.5 * (Z2.x - Z1.x));
     }
 }
 
@@ -191,7 +236,7 @@ __device__ __forceinline__ void loss_finalize(const LossFin& lf, int plane, doub
     }
 }
 
-__global__ void k_loss_finalize(LossFin lf) {
+static __global__ void k_loss_finalize(LossFin lf) {
     __shared__ double red[16 * 4];
     loss_finalize(lf, blockIdx.x, red, threadIdx.x, blockDim.x);
 }
@@ -200,43 +245,44 @@ __global__ void k_loss_finalize(LossFin lf) {
 #define COL_RES2 0  // (S0,S1) <- ( (S0 + conj(e) S1) g ,  e (S0 + conj(e) S1) g )
 #define COL_MUL 1   // S0 <- scale * m * S0   (conj_mult: conj(m))
 #define COL_MULR 2  // S0 <- g * S0            (real or complex g per gcplx)
-#define COL_FWD 3   // S0 <- scale * forward transform only (rows left in position order)
+#define COL_FWD 3   // S0 <- scale * transform only (dir 0 forward / 1 inverse), rows left in position order
+#define COL_FWD2 4  // as COL_FWD on both S0 and S1
 
 template <typename T>
 struct ColArgs {
     cx<T>* S0;
     cx<T>* S1;
-    const cx<T>* mult;   // complex multiplier [H][Wp], position order
-    const T* greal;      // real resolvent multiplier [H][Wp]
+    const cx<T>* mult;   // complex multiplier, same tiled layout, rows in position order
+    const T* greal;      // real resolvent multiplier
     const cx<T>* gcplx;  // complex resolvent multiplier (injected eigen arrays)
-    const cx<T>* tw;     // table exp(-2 pi i e / n), n = fd.n
-    const cx<T>* twH;    // table for H (outer twiddles of the split transform)
+    const cx<T>* tw;     // twiddle tables of the transform done by this launch
+    const cx<T>* twH;    // direct table for H (outer twiddles of the split transform)
     FftDesc fd;          // transform done by this launch
     FftDesc fa;          // first-stage factor of a split transform (outer != 0)
-    int H, Wh, Wp, batch;
-    int cshift, ntile;
+    SpecLayout lay;
+    int batch;
     int nseg, row_stride, seg_stride;
     int outer;      // split transform, middle stage: bit0 = w_H^(b*ka) on load, bit1 = conj of it on store
-    int dir;        // COL_FWD only: 0 forward, 1 inverse (strided short transforms of a split)
+    int dir;        // COL_FWD only: 0 forward, 1 inverse
     int conj_mult;
     T scale;
     LossFin lf;
 };
 
 template <typename T, int MODE>
-__global__ void __launch_bounds__(512) k_col(ColArgs<T> a) {
+__global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int n = a.fd.n, C = 1 << a.cshift;
-    const int arr = lds_round(n << a.cshift);
-    constexpr int NARR = (MODE == COL_RES2) ? 2 : 1;
+    const int n = a.fd.n, cs = a.lay.cs, C = 1 << cs;
+    const int arr = lds_round(n << cs);
+    constexpr int NARR = (MODE == COL_RES2 || MODE == COL_FWD2) ? 2 : 1;
     cx<T>* lds = reinterpret_cast<cx<T>*>(smem);
-    cx<T>* tw = lds + NARR * arr;
-    double* red = reinterpret_cast<double*>(tw + n);
+    cx<T>* twa = lds + NARR * arr;
+    double* red = reinterpret_cast<double*>(twa + tw_lds_entries(n));
 
     int bid = blockIdx.x;
-    const int tile = bid % a.ntile;
-    bid /= a.ntile;
+    const int tile = bid % a.lay.ntile;
+    bid /= a.lay.ntile;
     const int seg = bid % a.nseg;
     const int plane = bid / a.nseg;
 
@@ -248,57 +294,86 @@ __global__ void __launch_bounds__(512) k_col(ColArgs<T> a) {
         if (s >= 0 && s < a.lf.iter) return;
     }
 
-    load_table(tw, a.tw, n, tid, nt);
-    const int c0 = tile << a.cshift;
-    const size_t pbase = (size_t)plane * a.H;
+    const Tw<T> tw = tw_setup(twa, a.tw, n, tid, nt);
+    const size_t tbase = ((size_t)plane * a.lay.ntile + tile) * a.lay.H;  // in rows
+    const size_t mbase = (size_t)tile * a.lay.H;
     const int ka = a.outer ? freq_of_pos(a.fa, seg) : 0;
-    const int total = n << a.cshift;
-    for (int i = tid; i < total; i += nt) {
-        const int c = i & (C - 1), e = i >> a.cshift;
-        const size_t g = (pbase + (size_t)seg * a.seg_stride + (size_t)e * a.row_stride) * a.Wp + c0 + c;
-        cx<T> v0 = a.S0[g];
-        cx<T> v1;
-        if (NARR == 2) v1 = a.S1[g];
-        if (a.outer & 1) {
-            const cx<T> w = a.twH[e * ka];
-            v0 = v0 * w;
-            if (NARR == 2) v1 = v1 * w;
+    const int total = n << cs;
+    constexpr int UN = 8;  // loads in flight per thread and array
+    for (int i0 = tid; i0 < total; i0 += nt * UN) {
+        cx<T> v0[UN], v1[UN], w[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u * nt;
+            if (i < total) {
+                const int c = i & (C - 1), e = i >> cs;
+                const size_t g = ((tbase + (size_t)seg * a.seg_stride + (size_t)e * a.row_stride) << cs) + c;
+                v0[u] = a.S0[g];
+                if (NARR == 2) v1[u] = a.S1[g];
+                if (a.outer & 1) w[u] = a.twH[e * ka];
+            }
         }
-        lds[SW(i)] = v0;
-        if (NARR == 2) lds[arr + SW(i)] = v1;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u * nt;
+            if (i < total) {
+                if (a.outer & 1) {
+                    v0[u] = v0[u] * w[u];
+                    if (NARR == 2) v1[u] = v1[u] * w[u];
+                }
+                lds[SW(i)] = v0[u];
+                if (NARR == 2) lds[arr + SW(i)] = v1[u];
+            }
+        }
     }
     __syncthreads();
-    if (MODE == COL_FWD && a.dir == 1) {
-        fft_inverse<T>(lds, NARR, arr, tw, a.fd, a.cshift, tid, nt);
+    if ((MODE == COL_FWD || MODE == COL_FWD2) && a.dir == 1) {
+        fft_inverse<T>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
     } else {
-        fft_forward<T>(lds, NARR, arr, tw, a.fd, a.cshift, tid, nt);
+        fft_forward<T>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
     }
-    if (MODE != COL_FWD) {
-        for (int i = tid; i < total; i += nt) {
-            const int c = i & (C - 1), e = i >> a.cshift;
-            const size_t mrow = (size_t)seg * a.seg_stride + (size_t)e * a.row_stride;
-            const size_t gi = mrow * a.Wp + c0 + c;
-            const int li = SW(i);
-            if (MODE == COL_RES2) {
-                const cx<T> ek = a.mult[gi];
-                cx<T> U = lds[li] + mulc(lds[arr + li], ek);
-                if (a.gcplx) U = U * a.gcplx[gi]; else U = U * a.greal[gi];
-                lds[li] = U;
-                lds[arr + li] = ek * U;
-            } else if (MODE == COL_MUL) {
-                const cx<T> m = a.mult[gi];
-                const cx<T> x = lds[li];
-                lds[li] = (a.conj_mult ? mulc(x, m) : x * m) * a.scale;
-            } else {
-                if (a.gcplx) lds[li] = lds[li] * a.gcplx[gi]; else lds[li] = lds[li] * a.greal[gi];
+    if (MODE != COL_FWD && MODE != COL_FWD2) {
+        for (int i0 = tid; i0 < total; i0 += nt * UN) {
+            cx<T> mm[UN], gc[UN];
+            T gr[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + u * nt;
+                if (i < total) {
+                    const int c = i & (C - 1), e = i >> cs;
+                    const size_t gi = ((mbase + (size_t)seg * a.seg_stride + (size_t)e * a.row_stride) << cs) + c;
+                    if (MODE != COL_MULR) mm[u] = a.mult[gi];
+                    if (MODE != COL_MUL) {
+                        if (a.gcplx) gc[u] = a.gcplx[gi]; else gr[u] = a.greal[gi];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + u * nt;
+                if (i < total) {
+                    const int li = SW(i);
+                    if (MODE == COL_RES2) {
+                        const cx<T> ek = mm[u];
+                        cx<T> U = lds[li] + mulc(lds[arr + li], ek);
+                        if (a.gcplx) U = U * gc[u]; else U = U * gr[u];
+                        lds[li] = U;
+                        lds[arr + li] = ek * U;
+                    } else if (MODE == COL_MUL) {
+                        const cx<T> x = lds[li];
+                        lds[li] = (a.conj_mult ? mulc(x, mm[u]) : x * mm[u]) * a.scale;
+                    } else {
+                        if (a.gcplx) lds[li] = lds[li] * gc[u]; else lds[li] = lds[li] * gr[u];
+                    }
+                }
             }
         }
         __syncthreads();
-        fft_inverse<T>(lds, NARR, arr, tw, a.fd, a.cshift, tid, nt);
+        fft_inverse<T>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
     }
     for (int i = tid; i < total; i += nt) {
-        const int c = i & (C - 1), e = i >> a.cshift;
-        const size_t g = (pbase + (size_t)seg * a.seg_stride + (size_t)e * a.row_stride) * a.Wp + c0 + c;
+        const int c = i & (C - 1), e = i >> cs;
+        const size_t g = ((tbase + (size_t)seg * a.seg_stride + (size_t)e * a.row_stride) << cs) + c;
         cx<T> v0 = lds[SW(i)];
         cx<T> v1;
         if (NARR == 2) v1 = lds[arr + SW(i)];
@@ -316,19 +391,22 @@ __global__ void __launch_bounds__(512) k_col(ColArgs<T> a) {
 // ----------------------------------------------------------------- arguments of row kernels
 template <typename T>
 struct RowCommon {
-    int H, W, Wp, batch;
+    int H, W, batch;
     int V_groups;        // W / V
     FftDesc fw;
-    const cx<T>* twW;    // global table for W
+    SpecLayout lay;
+    const cx<T>* twW;    // global twiddle tables for W
     cx<T>* S0;
     cx<T>* S1;
     const cx<T>* eDrow;  // row-spectral D table (W/2+1 entries) or null = 2-tap stencils
     const int* stop;     // per image, may be null
     double* partials;    // [batch*H][4]
     int do_consume, do_produce;
+    long long* dbg;      // diagnostic builds only: per-workgroup phase stamps (null = off)
+    int dbg_mode;        // diagnostic: bit0 skip the transforms, bit1 skip pack/unpack, bit2 skip iterate stores
 };
 
-// LDS carve-up shared by all row kernels: data | twiddles | edge values | reduction scratch
+// LDS carve-up shared by all row kernels: data | twiddles | reduction scratch | edge values
 template <typename T>
 struct RowLds {
     cx<T>* data;
@@ -338,540 +416,464 @@ struct RowLds {
     __device__ __forceinline__ RowLds(unsigned char* smem, int W) {
         data = reinterpret_cast<cx<T>*>(smem);
         tw = data + lds_round(W);
-        red = reinterpret_cast<double*>(tw + W);
+        red = reinterpret_cast<double*>(tw + tw_lds_entries(W));
         edge = reinterpret_cast<T*>(red + 16 * 4);
     }
 };
 template <typename T>
 __host__ __device__ inline size_t row_lds_bytes(int W, int V) {
-    return (size_t)(lds_round(W) + W) * sizeof(cx<T>) + 16 * 4 * sizeof(double) + (size_t)(W / V + 8) * sizeof(T);
+    return (size_t)(lds_round(W) + tw_lds_entries(W)) * sizeof(cx<T>) + 16 * 4 * sizeof(double) + (size_t)(W / V + 8) * sizeof(T);
 }
 
-// Run a second inverse transform of (U * eD) to obtain D applied to the first packed row
-// (row-spectral D).  On return data[j].x = (D a)[j]; the previous contents are lost.
-template <typename T>
-__device__ __forceinline__ void row_spectral_D(RowLds<T>& L, const RowCommon<T>& c, const cx<T>* srcA, int tid, int nt) {
-    row_pack_mul(L.data, c.fw, c.W, srcA, c.eDrow, tid, nt);
-    __syncthreads();
-    fft_inverse<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
-}
+// ============================================================ solver policies (one pixel group)
+// step(): o = offset of the group's first pixel in an image array.  When `consume`, (u, k, du) are the
+// inverse-transformed outputs of the column stage at these pixels (resolvent output, K applied to it,
+// D applied to it): finish the iteration in place.  When `produce`, return the inputs of the next
+// column stage: re (identity path, without the D^T part), im (K^T path) and s, the array whose
+// D^T image is added to re.  acc: sums of |d| and d^2 for the loss pairs.
 
-// ------------------------------------------------------------------------ primal DR row kernel
-// primal_dr/algorithm.py:94-129.  consume: finish iteration with u = F^-1 U, v0 = F^-1 (eK U):
-//   z1 += rho (u - x), z2 += rho ([v0, Du, Du] - y) with x = clip(z1), y = prox(z2) recomputed;
-// produce: x, y of the new z, a = 2y - z2, transform inputs p = 2x - z1 + D^T(a1 + a2), q = a0.
+// primal_dr/algorithm.py:94-129
 template <typename T>
-struct PdrArgs {
-    RowCommon<T> c;
-    T* z1; T* z20; T* z21; T* z22;
-    const T* b;
-    T t, rho, tg;  // tg = t*gamma
-    T l2div;       // 2t + 1
-    int objective;
+struct PdrP {
+    struct Args {
+        T* __restrict__ z1; T* __restrict__ z20; T* __restrict__ z21; T* __restrict__ z22;
+        const T* __restrict__ b;
+        T t, rho, tg, l2div;  // tg = t*gamma, l2div = 2t + 1
+        int objective;
+    };
+    static __device__ __forceinline__ void xy(const Args& a, T z1, T z20, T z21, T z22, T b, T& x, T& y0, T& y1, T& y2) {
+        x = clip01(z1);                                                                           // pdr:96
+        if (a.objective == 0) y0 = b + soft(z20 - b, a.t); else y0 = b + (z20 - b) / a.l2div;      // pdr:105 / 110
+        iso(z21, z22, a.tg, y1, y2);                                                              // pdr:103 / 108
+    }
+    template <int V>
+    struct St {
+        T z1[V], z20[V], z21[V], z22[V], b[V];
+    };
+    template <int V>
+    static __device__ __forceinline__ void load(const Args& a, size_t o, St<V>& q) {
+        vload<T, V>(a.z1 + o, q.z1);
+        vload<T, V>(a.z20 + o, q.z20);
+        vload<T, V>(a.z21 + o, q.z21);
+        vload<T, V>(a.z22 + o, q.z22);
+        vload<T, V>(a.b + o, q.b);
+    }
+    template <int V>
+    static __device__ __forceinline__ void step(const Args& a, bool consume, bool produce, size_t o, const T (&u)[V], const T (&k)[V], const T (&du)[V],
+                                                T (&re)[V], T (&im)[V], T (&s)[V], double (&acc)[4]) {
+        St<V> q;
+        load<V>(a, o, q);
+        step_regs<V>(a, consume, produce, o, q, u, k, du, re, im, s, acc);
+    }
+    template <int V>
+    static __device__ __forceinline__ void step_regs(const Args& a, bool consume, bool produce, size_t o, St<V>& q, const T (&u)[V], const T (&k)[V],
+                                                     const T (&du)[V], T (&re)[V], T (&im)[V], T (&s)[V], double (&acc)[4]) {
+        T (&z1)[V] = q.z1; T (&z20)[V] = q.z20; T (&z21)[V] = q.z21; T (&z22)[V] = q.z22; T (&b)[V] = q.b;
+        if (consume) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                T x, y0, y1, y2;
+                xy(a, z1[v], z20[v], z21[v], z22[v], b[v], x, y0, y1, y2);
+                const T n1 = z1[v] + a.rho * (u[v] - x);                                          // pdr:128
+                const T d1 = n1 - z1[v], d2 = n1 - b[v];
+                acc[0] += (double)t_abs(d1); acc[1] += (double)d1 * (double)d1;
+                acc[2] += (double)t_abs(d2); acc[3] += (double)d2 * (double)d2;
+                z1[v] = n1;
+                z20[v] = z20[v] + a.rho * (k[v] - y0);                                            // pdr:129
+                z21[v] = z21[v] + a.rho * (du[v] - y1);
+                z22[v] = z22[v] + a.rho * (du[v] - y2);
+            }
+            vstore<T, V>(a.z1 + o, z1);
+            vstore<T, V>(a.z20 + o, z20);
+            vstore<T, V>(a.z21 + o, z21);
+            vstore<T, V>(a.z22 + o, z22);
+        }
+        if (produce) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                T x, y0, y1, y2;
+                xy(a, z1[v], z20[v], z21[v], z22[v], b[v], x, y0, y1, y2);
+                re[v] = (T)2 * x - z1[v];                                                         // pdr:119
+                im[v] = (T)2 * y0 - z20[v];                                                       // pdr:115
+                s[v] = ((T)2 * y1 - z21[v]) + ((T)2 * y2 - z22[v]);
+            }
+        }
+    }
 };
 
+// primal_dual_dr/algorithm.py:65-101
 template <typename T>
-__device__ __forceinline__ void pdr_xy(const PdrArgs<T>& a, T z1, T z20, T z21, T z22, T b, T& x, T& y0, T& y1, T& y2) {
-    x = clip01(z1);
-    if (a.objective == 0) y0 = b + soft(z20 - b, a.t); else y0 = b + (z20 - b) / a.l2div;
-    iso(z21, z22, a.tg, y1, y2);
-}
+struct PddrP {
+    struct Args {
+        T* __restrict__ p; T* __restrict__ q0; T* __restrict__ q1; T* __restrict__ q2;
+        const T* __restrict__ b;
+        T t, it, rho, itg;  // it = 1/t, itg = gamma/t
+    };
+    static __device__ __forceinline__ void xz(const Args& a, T p, T q0, T q1, T q2, T b, T& x, T& z0, T& z1, T& z2) {
+        x = clip01(p);                                                                            // pddr:66
+        z0 = q0 - a.t * b - a.t * soft(a.it * q0 - b, a.it);                                      // pddr:69
+        T i1, i2;
+        iso(a.it * q1, a.it * q2, a.itg, i1, i2);                                                 // pddr:70
+        z1 = q1 - a.t * i1;
+        z2 = q2 - a.t * i2;
+    }
+    template <int V>
+    struct St {
+        T p[V], q0[V], q1[V], q2[V], b[V];
+    };
+    template <int V>
+    static __device__ __forceinline__ void load(const Args& a, size_t o, St<V>& q) {
+        vload<T, V>(a.p + o, q.p);
+        vload<T, V>(a.q0 + o, q.q0);
+        vload<T, V>(a.q1 + o, q.q1);
+        vload<T, V>(a.q2 + o, q.q2);
+        vload<T, V>(a.b + o, q.b);
+    }
+    template <int V>
+    static __device__ __forceinline__ void step(const Args& a, bool consume, bool produce, size_t o, const T (&w)[V], const T (&kw)[V], const T (&dw)[V],
+                                                T (&re)[V], T (&im)[V], T (&s)[V], double (&acc)[4]) {
+        St<V> q;
+        load<V>(a, o, q);
+        step_regs<V>(a, consume, produce, o, q, w, kw, dw, re, im, s, acc);
+    }
+    template <int V>
+    static __device__ __forceinline__ void step_regs(const Args& a, bool consume, bool produce, size_t o, St<V>& st, const T (&w)[V], const T (&kw)[V],
+                                                     const T (&dw)[V], T (&re)[V], T (&im)[V], T (&s)[V], double (&acc)[4]) {
+        T (&p)[V] = st.p; T (&q0)[V] = st.q0; T (&q1)[V] = st.q1; T (&q2)[V] = st.q2; T (&b)[V] = st.b;
+        if (consume) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                T x, z0, z1, z2;
+                xz(a, p[v], q0[v], q1[v], q2[v], b[v], x, z0, z1, z2);
+                const T o0 = (T)2 * z0 - q0[v], o1 = (T)2 * z1 - q1[v], o2 = (T)2 * z2 - q2[v];  // pddr:77-80
+                p[v] = p[v] + a.rho * (w[v] - x);                                                 // pddr:100
+                q0[v] = q0[v] + a.rho * ((a.t * kw[v] + o0) - z0);                                // pddr:90-101
+                q1[v] = q1[v] + a.rho * ((a.t * dw[v] + o1) - z1);
+                q2[v] = q2[v] + a.rho * ((a.t * dw[v] + o2) - z2);
+                const T d = clip01(p[v]) - b[v];                                                  // pddr:104
+                acc[0] += (double)t_abs(d); acc[1] += (double)d * (double)d;
+            }
+            vstore<T, V>(a.p + o, p);
+            vstore<T, V>(a.q0 + o, q0);
+            vstore<T, V>(a.q1 + o, q1);
+            vstore<T, V>(a.q2 + o, q2);
+        }
+        if (produce) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                T x, z0, z1, z2;
+                xz(a, p[v], q0[v], q1[v], q2[v], b[v], x, z0, z1, z2);
+                re[v] = (T)2 * x - p[v];                                                          // pddr:76
+                im[v] = -a.t * ((T)2 * z0 - q0[v]);                                               // pddr:83
+                s[v] = -a.t * (((T)2 * z1 - q1[v]) + ((T)2 * z2 - q2[v]));
+            }
+        }
+    }
+};
 
-template <typename T, int V, int NG, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_pdr_row(PdrArgs<T> a) {
+// admm/algorithm.py:69-115 (and the solves of admm:118-132, 160-173)
+template <typename T>
+struct AdmmP {
+    struct Args {
+        T* __restrict__ u; T* __restrict__ w; T* __restrict__ y0; T* __restrict__ y1; T* __restrict__ y2; T* __restrict__ z0; T* __restrict__ z1; T* __restrict__ z2;
+        const T* __restrict__ b;
+        T* __restrict__ sol;  // when non-null the consume step stores x (the look-ahead solution of admm:118-132)
+        T t, it, rho, omr, itg, l2div;  // it = 1/t, omr = 1 - rho, itg = gamma/t, l2div = 2/t + 1
+        int objective;
+        int sol_only;  // consume computes x and the loss only (final solve, admm:160-173)
+    };
+    template <int V>
+    struct St {
+        T b[V], u[V], w[V], y0[V], y1[V], y2[V], z0[V], z1[V], z2[V];
+    };
+    template <int V>
+    static __device__ __forceinline__ void load(const Args& a, size_t o, St<V>& q) {
+        vload<T, V>(a.b + o, q.b);
+        if (a.sol_only) return;
+        vload<T, V>(a.u + o, q.u);
+        vload<T, V>(a.w + o, q.w);
+        vload<T, V>(a.y0 + o, q.y0);
+        vload<T, V>(a.y1 + o, q.y1);
+        vload<T, V>(a.y2 + o, q.y2);
+        vload<T, V>(a.z0 + o, q.z0);
+        vload<T, V>(a.z1 + o, q.z1);
+        vload<T, V>(a.z2 + o, q.z2);
+    }
+    template <int V>
+    static __device__ __forceinline__ void step(const Args& a, bool consume, bool produce, size_t o, const T (&x)[V], const T (&kx)[V], const T (&dx)[V],
+                                                T (&re)[V], T (&im)[V], T (&s)[V], double (&acc)[4]) {
+        St<V> q;
+        load<V>(a, o, q);
+        step_regs<V>(a, consume, produce, o, q, x, kx, dx, re, im, s, acc);
+    }
+    template <int V>
+    static __device__ __forceinline__ void step_regs(const Args& a, bool consume, bool produce, size_t o, St<V>& st, const T (&x)[V], const T (&kx)[V],
+                                                     const T (&dx)[V], T (&re)[V], T (&im)[V], T (&s)[V], double (&acc)[4]) {
+        T (&b)[V] = st.b; T (&u)[V] = st.u; T (&w)[V] = st.w; T (&y0)[V] = st.y0; T (&y1)[V] = st.y1; T (&y2)[V] = st.y2;
+        T (&z0)[V] = st.z0; T (&z1)[V] = st.z1; T (&z2)[V] = st.z2;
+        if (consume) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const T d = x[v] - b[v];
+                acc[0] += (double)t_abs(d); acc[1] += (double)d * (double)d;
+            }
+            if (a.sol) vstore<T, V>(a.sol + o, x);
+        }
+        if (a.sol_only) return;
+        if (consume) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const T un = clip01(a.rho * x[v] + a.omr * u[v] + a.it * w[v]);                   // admm:87-88
+                const T pp0 = a.rho * kx[v] + a.omr * y0[v] + a.it * z0[v];                       // admm:98
+                const T pp1 = a.rho * dx[v] + a.omr * y1[v] + a.it * z1[v];
+                const T pp2 = a.rho * dx[v] + a.omr * y2[v] + a.it * z2[v];
+                T y0n, y1n, y2n;
+                if (a.objective == 0) y0n = b[v] + soft(pp0 - b[v], a.it); else y0n = b[v] + (pp0 - b[v]) / a.l2div;  // admm:99-104
+                iso(pp1, pp2, a.itg, y1n, y2n);                                                   // admm:105
+                w[v] = w[v] + a.t * (x[v] - un);                                                  // admm:108
+                z0[v] = z0[v] + a.t * (kx[v] - y0n);                                              // admm:109
+                z1[v] = z1[v] + a.t * (dx[v] - y1n);
+                z2[v] = z2[v] + a.t * (dx[v] - y2n);
+                u[v] = un; y0[v] = y0n; y1[v] = y1n; y2[v] = y2n;
+            }
+            vstore<T, V>(a.u + o, u);
+            vstore<T, V>(a.w + o, w);
+            vstore<T, V>(a.y0 + o, y0);
+            vstore<T, V>(a.y1 + o, y1);
+            vstore<T, V>(a.y2 + o, y2);
+            vstore<T, V>(a.z0 + o, z0);
+            vstore<T, V>(a.z1 + o, z1);
+            vstore<T, V>(a.z2 + o, z2);
+        }
+        if (produce) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                re[v] = u[v] - a.it * w[v];                                                       // admm:85
+                im[v] = y0[v] - a.it * z0[v];
+                s[v] = (y1[v] + y2[v]) - a.it * (z1[v] + z2[v]);
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------- fused solver row kernel
+// One workgroup per image row (grid-stride over rows).  Per row:
+//   consume: pack (S0, S1) -> inverse transform -> per pixel (u, K u) and D u (2-tap stencil through
+//            LDS, or a second inverse transform of eD * S0 when SPEC);
+//   per pixel group: policy step (iterate update, loss sums, next transform inputs) written back in
+//            place into LDS as re + D^T s (stencil; the last pixel of a group is fixed up after a
+//            barrier from the neighbour's edge value) + i im;
+//   produce: forward transform -> separate the two half-spectra -> (S0, S1)
+//            (SPEC: a second forward transform of s adds conj(eD) * F(s) to S0).
+// PF: every global load of a row (half-spectra and iterate arrays) is issued at the top of the row
+// iteration and held in registers, so that ~100 KB per workgroup are in flight while the previous
+// phase drains and the iterate loads hide behind the pack and inverse-transform phases; without
+// it each phase is a chain of exposed HBM round trips and a CU keeps far too few bytes in flight.
+template <typename T, class P, int V, int NG, bool SPEC, int PF, int WF, int MAXT, int MINW>
+__global__ void __launch_bounds__(MAXT, MINW) k_solver_row(RowCommon<T> c, typename P::Args a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const RowCommon<T>& c = a.c;
     const int tid = threadIdx.x, nt = blockDim.x, W = c.W;
     RowLds<T> L(smem, W);
-    load_table(L.tw, c.twW, W, tid, nt);
-    const bool spec = c.eDrow != nullptr;
+    const Tw<T> tw = tw_setup(L.tw, c.twW, W, tid, nt);
     const int nrows = c.batch * c.H;
+    constexpr int NH = SPEC ? NG : 1;
+    constexpr int KP = (V * NG) / 2 + 1;  // half-spectrum entries per thread when nt = W / (V*NG)
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int plane = row / c.H;
         if (c.stop && c.stop[plane] >= 0) continue;
-        const size_t ro = (size_t)row * W, so = (size_t)row * c.Wp;
-        T u[NG][V], k0[NG][V], du[NG][V];
+        const size_t ro = (size_t)row * W;
+        const SpecRow sr = spec_row(c.lay, plane, row - plane * c.H);
+        T uprev[NG];
+        T duh[NH][V], sh[NH][V];
+        // PF == 1: iterate loads at the row top (needs ~250 registers); PF == 2: iterate loads of all
+        // pixel groups issued together at the start of the per-pixel phase (fits 128 registers).
+        // PF == 3: rolling double buffer, the loads of group g+1 are issued before group g is processed.
+        constexpr int NPF = PF == 3 ? 2 : (PF ? NG : 1);
+        constexpr int KPF = PF == 1 ? KP : 1;
+        typename P::template St<V> stq[NPF];
+        cx<T> pU[KPF], pV[KPF];
+        if (PF == 1) {
+            if (c.do_consume) row_pack_load<T, KPF>(pU, pV, W, c.S0, sr, c.S1, sr, tid, nt);
+#pragma unroll
+            for (int g = 0; g < NPF; ++g) {
+                const int j = (tid + g * nt) * V;
+                if (j < W) P::template load<V>(a, ro + j, stq[g]);
+            }
+        }
         __syncthreads();
+#define DDN_STAMP(i) if (c.dbg && tid == 0 && row == (int)blockIdx.x + (int)gridDim.x) c.dbg[blockIdx.x * 16 + (i)] = clock64();
+        DDN_STAMP(0)
         if (c.do_consume) {
-            if (spec) {
-                row_spectral_D(L, c, c.S0 + so, tid, nt);
+            if (SPEC) {
+                row_pack_mul<T, WF>(L.data, c.fw, W, c.S0, sr, c.eDrow, tid, nt);
+                __syncthreads();
+                fft_inv<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int j = (tid + g * nt) * V;
                     if (j < W) {
 #pragma unroll
-                        for (int v = 0; v < V; ++v) du[g][v] = L.data[SW(j + v)].x;
+                        for (int v = 0; v < V; ++v) duh[g % NH][v] = L.data[SW(j + v)].x;
                     }
                 }
                 __syncthreads();
             }
-            row_pack(L.data, c.fw, W, c.S0 + so, c.S1 + so, tid, nt);
+            if (!(c.dbg_mode & 2)) {
+                if (PF == 1) row_pack_store<T, KPF, WF>(L.data, c.fw, W, pU, pV, tid, nt);
+                else row_pack<T, KP, WF>(L.data, c.fw, W, c.S0, sr, c.S1, sr, tid, nt);
+            } else if (PF == 1) {
+                T sacc = 0;
+#pragma unroll
+                for (int i = 0; i < KPF; ++i) sacc += pU[i].x + pV[i].y;
+                L.data[SW(tid)].x = sacc;
+            }
             __syncthreads();
-            fft_inverse<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
+            DDN_STAMP(1)
+            if (!(c.dbg_mode & 1)) fft_inv<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+            DDN_STAMP(2)
+            if (!SPEC) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int j = (tid + g * nt) * V;
-                if (j < W) {
-                    T prev = L.data[SW(j == 0 ? W - 1 : j - 1)].x;
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const cx<T> e = L.data[SW(j + v)];
-                        u[g][v] = e.x;
-                        k0[g][v] = e.y;
-                        if (!spec) du[g][v] = e.x - prev;
-                        prev = e.x;
-                    }
+                for (int g = 0; g < NG; ++g) {
+                    const int j = (tid + g * nt) * V;
+                    if (j < W) uprev[g] = L.data[SW(j == 0 ? W - 1 : j - 1)].x;
                 }
+                __syncthreads();
             }
         }
-        T pb[NG][V], q0[NG][V], sv[NG][V];
         double acc[4] = {0, 0, 0, 0};
+        DDN_STAMP(3)
+        if (PF == 2) {
+#pragma unroll
+            for (int g = 0; g < NPF; ++g) {
+                const int j = (tid + g * nt) * V;
+                if (j < W) P::template load<V>(a, ro + j, stq[g]);
+            }
+        }
+        if (PF == 3) {
+            if (tid * V < W) P::template load<V>(a, ro + tid * V, stq[0]);
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int j = (tid + g * nt) * V;
+            if (PF == 3 && g + 1 < NG) {
+                const int jn = (tid + (g + 1) * nt) * V;
+                if (jn < W) P::template load<V>(a, ro + jn, stq[(g + 1) % NPF]);
+            }
             if (j < W) {
-                T z1[V], z20[V], z21[V], z22[V], b[V];
-                vload<T, V>(a.z1 + ro + j, z1);
-                vload<T, V>(a.z20 + ro + j, z20);
-                vload<T, V>(a.z21 + ro + j, z21);
-                vload<T, V>(a.z22 + ro + j, z22);
-                vload<T, V>(a.b + ro + j, b);
+                T u[V], k[V], du[V], re[V], im[V], s[V];
                 if (c.do_consume) {
+                    T prev = SPEC ? (T)0 : uprev[g];
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
-                        T x, y0, y1, y2;
-                        pdr_xy(a, z1[v], z20[v], z21[v], z22[v], b[v], x, y0, y1, y2);
-                        const T n1 = z1[v] + a.rho * (u[g][v] - x);
-                        const T d1 = n1 - z1[v], d2 = n1 - b[v];
-                        acc[0] += (double)t_abs(d1); acc[1] += (double)d1 * (double)d1;
-                        acc[2] += (double)t_abs(d2); acc[3] += (double)d2 * (double)d2;
-                        z1[v] = n1;
-                        z20[v] = z20[v] + a.rho * (k0[g][v] - y0);
-                        z21[v] = z21[v] + a.rho * (du[g][v] - y1);
-                        z22[v] = z22[v] + a.rho * (du[g][v] - y2);
+                        const cx<T> e = L.data[SW(j + v)];
+                        u[v] = e.x;
+                        k[v] = e.y;
+                        du[v] = SPEC ? duh[g % NH][v] : e.x - prev;
+                        prev = e.x;
                     }
-                    vstore<T, V>(a.z1 + ro + j, z1);
-                    vstore<T, V>(a.z20 + ro + j, z20);
-                    vstore<T, V>(a.z21 + ro + j, z21);
-                    vstore<T, V>(a.z22 + ro + j, z22);
                 }
+                if (PF) P::template step_regs<V>(a, c.do_consume != 0, c.do_produce != 0, ro + j, stq[g % NPF], u, k, du, re, im, s, acc);
+                else P::template step<V>(a, c.do_consume != 0, c.do_produce != 0, ro + j, u, k, du, re, im, s, acc);
                 if (c.do_produce) {
+                    if (SPEC) {
 #pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        T x, y0, y1, y2;
-                        pdr_xy(a, z1[v], z20[v], z21[v], z22[v], b[v], x, y0, y1, y2);
-                        pb[g][v] = (T)2 * x - z1[v];
-                        q0[g][v] = (T)2 * y0 - z20[v];
-                        sv[g][v] = ((T)2 * y1 - z21[v]) + ((T)2 * y2 - z22[v]);
+                        for (int v = 0; v < V; ++v) {
+                            sh[g % NH][v] = s[v];
+                            L.data[SW(j + v)] = mk<T>(re[v], im[v]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < V; ++v) {
+                            const T nx = (v + 1 < V) ? s[(v + 1) % V] : (T)0;
+                            L.data[SW(j + v)] = mk<T>(re[v] + (s[v] - nx), im[v]);
+                        }
+                        L.edge[tid + g * nt] = s[0];
                     }
-                    L.edge[tid + g * nt] = sv[g][0];
                 }
             }
         }
+        DDN_STAMP(4)
         if (c.do_consume) {
             block_reduce<4>(acc, L.red, tid, nt);
             if (tid == 0) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) c.partials[(size_t)row * 4 + s] = acc[s];
+                for (int q = 0; q < 4; ++q) c.partials[(size_t)row * 4 + q] = acc[q];
             }
         }
         __syncthreads();
+        DDN_STAMP(5)
         if (c.do_produce) {
-            if (spec) {
-                // first transform: s alone, D^T applied as conj(eD) in the row spectrum
+            if (!SPEC) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int j = (tid + g * nt) * V;
+                    if (j < W) {
+                        const int grp = tid + g * nt;
+                        const int li = SW(j + V - 1);
+                        L.data[li].x -= L.edge[grp + 1 == c.V_groups ? 0 : grp + 1];
+                    }
+                }
+                __syncthreads();
+            }
+            DDN_STAMP(6)
+            if (!(c.dbg_mode & 1)) fft_fwd<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+            DDN_STAMP(7)
+            if (!(c.dbg_mode & 2)) row_unpack<T, WF>(L.data, c.fw, W, c.S0, sr, c.S1, sr, nullptr, false, tid, nt);
+            DDN_STAMP(8)
+            if (SPEC) {
+                __syncthreads();
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int j = (tid + g * nt) * V;
                     if (j < W) {
 #pragma unroll
-                        for (int v = 0; v < V; ++v) L.data[SW(j + v)] = mk<T>(sv[g][v], 0);
+                        for (int v = 0; v < V; ++v) L.data[SW(j + v)] = mk<T>(sh[g % NH][v], 0);
                     }
                 }
                 __syncthreads();
-                fft_forward<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
-                row_unpack<T>(L.data, c.fw, W, c.S0 + so, nullptr, c.eDrow, false, tid, nt);
-                __syncthreads();
+                fft_fwd<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+                row_unpack<T, WF>(L.data, c.fw, W, c.S0, sr, nullptr, sr, c.eDrow, true, tid, nt);
             }
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int j = (tid + g * nt) * V;
-                if (j < W) {
-                    const int grp = tid + g * nt;
-                    const T snext = L.edge[grp + 1 == c.V_groups ? 0 : grp + 1];
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const T nx = (v + 1 < V) ? sv[g][(v + 1) % V] : snext;
-                        const T re = spec ? pb[g][v] : pb[g][v] + (sv[g][v] - nx);
-                        L.data[SW(j + v)] = mk<T>(re, q0[g][v]);
-                    }
-                }
-            }
-            __syncthreads();
-            fft_forward<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
-            row_unpack<T>(L.data, c.fw, W, c.S0 + so, c.S1 + so, nullptr, spec, tid, nt);
         }
     }
 }
 
-// ---------------------------------------------------------------- primal-dual DR row kernel
-// primal_dual_dr/algorithm.py:65-101.
-template <typename T>
-struct PddrArgs {
-    RowCommon<T> c;
-    T* p; T* q0; T* q1; T* q2;
-    const T* b;
-    T t, it, rho, itg;  // it = 1/t, itg = gamma/t
-};
-
-template <typename T>
-__device__ __forceinline__ void pddr_xz(const PddrArgs<T>& a, T p, T q0, T q1, T q2, T b, T& x, T& z0, T& z1, T& z2) {
-    x = clip01(p);
-    z0 = q0 - a.t * b - a.t * soft(a.it * q0 - b, a.it);
-    T i1, i2;
-    iso(a.it * q1, a.it * q2, a.itg, i1, i2);
-    z1 = q1 - a.t * i1;
-    z2 = q2 - a.t * i2;
-}
-
-template <typename T, int V, int NG, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_pddr_row(PddrArgs<T> a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const RowCommon<T>& c = a.c;
-    const int tid = threadIdx.x, nt = blockDim.x, W = c.W;
-    RowLds<T> L(smem, W);
-    load_table(L.tw, c.twW, W, tid, nt);
-    const bool spec = c.eDrow != nullptr;
-    const int nrows = c.batch * c.H;
-    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const int plane = row / c.H;
-        if (c.stop && c.stop[plane] >= 0) continue;
-        const size_t ro = (size_t)row * W, so = (size_t)row * c.Wp;
-        T w[NG][V], kw[NG][V], dw[NG][V];
-        __syncthreads();
-        if (c.do_consume) {
-            if (spec) {
-                row_spectral_D(L, c, c.S0 + so, tid, nt);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const int j = (tid + g * nt) * V;
-                    if (j < W) {
-#pragma unroll
-                        for (int v = 0; v < V; ++v) dw[g][v] = L.data[SW(j + v)].x;
-                    }
-                }
-                __syncthreads();
-            }
-            row_pack(L.data, c.fw, W, c.S0 + so, c.S1 + so, tid, nt);
-            __syncthreads();
-            fft_inverse<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int j = (tid + g * nt) * V;
-                if (j < W) {
-                    T prev = L.data[SW(j == 0 ? W - 1 : j - 1)].x;
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const cx<T> e = L.data[SW(j + v)];
-                        w[g][v] = e.x;
-                        kw[g][v] = e.y;
-                        if (!spec) dw[g][v] = e.x - prev;
-                        prev = e.x;
-                    }
-                }
-            }
-        }
-        T pb[NG][V], qin[NG][V], sv[NG][V];
-        double acc[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int j = (tid + g * nt) * V;
-            if (j < W) {
-                T p[V], q0[V], q1[V], q2[V], b[V];
-                vload<T, V>(a.p + ro + j, p);
-                vload<T, V>(a.q0 + ro + j, q0);
-                vload<T, V>(a.q1 + ro + j, q1);
-                vload<T, V>(a.q2 + ro + j, q2);
-                vload<T, V>(a.b + ro + j, b);
-                if (c.do_consume) {
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        T x, z0, z1, z2;
-                        pddr_xz(a, p[v], q0[v], q1[v], q2[v], b[v], x, z0, z1, z2);
-                        const T o0 = (T)2 * z0 - q0[v], o1 = (T)2 * z1 - q1[v], o2 = (T)2 * z2 - q2[v];
-                        p[v] = p[v] + a.rho * (w[g][v] - x);
-                        q0[v] = q0[v] + a.rho * ((a.t * kw[g][v] + o0) - z0);
-                        q1[v] = q1[v] + a.rho * ((a.t * dw[g][v] + o1) - z1);
-                        q2[v] = q2[v] + a.rho * ((a.t * dw[g][v] + o2) - z2);
-                        const T d = clip01(p[v]) - b[v];
-                        acc[0] += (double)t_abs(d); acc[1] += (double)d * (double)d;
-                    }
-                    vstore<T, V>(a.p + ro + j, p);
-                    vstore<T, V>(a.q0 + ro + j, q0);
-                    vstore<T, V>(a.q1 + ro + j, q1);
-                    vstore<T, V>(a.q2 + ro + j, q2);
-                }
-                if (c.do_produce) {
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        T x, z0, z1, z2;
-                        pddr_xz(a, p[v], q0[v], q1[v], q2[v], b[v], x, z0, z1, z2);
-                        pb[g][v] = (T)2 * x - p[v];
-                        qin[g][v] = -a.t * ((T)2 * z0 - q0[v]);
-                        sv[g][v] = -a.t * (((T)2 * z1 - q1[v]) + ((T)2 * z2 - q2[v]));
-                    }
-                    L.edge[tid + g * nt] = sv[g][0];
-                }
-            }
-        }
-        if (c.do_consume) {
-            block_reduce<4>(acc, L.red, tid, nt);
-            if (tid == 0) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) c.partials[(size_t)row * 4 + s] = acc[s];
-            }
-        }
-        __syncthreads();
-        if (c.do_produce) {
-            if (spec) {
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const int j = (tid + g * nt) * V;
-                    if (j < W) {
-#pragma unroll
-                        for (int v = 0; v < V; ++v) L.data[SW(j + v)] = mk<T>(sv[g][v], 0);
-                    }
-                }
-                __syncthreads();
-                fft_forward<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
-                row_unpack<T>(L.data, c.fw, W, c.S0 + so, nullptr, c.eDrow, false, tid, nt);
-                __syncthreads();
-            }
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int j = (tid + g * nt) * V;
-                if (j < W) {
-                    const int grp = tid + g * nt;
-                    const T snext = L.edge[grp + 1 == c.V_groups ? 0 : grp + 1];
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const T nx = (v + 1 < V) ? sv[g][(v + 1) % V] : snext;
-                        const T re = spec ? pb[g][v] : pb[g][v] + (sv[g][v] - nx);
-                        L.data[SW(j + v)] = mk<T>(re, qin[g][v]);
-                    }
-                }
-            }
-            __syncthreads();
-            fft_forward<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
-            row_unpack<T>(L.data, c.fw, W, c.S0 + so, c.S1 + so, nullptr, spec, tid, nt);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------ ADMM row kernel
-// admm/algorithm.py:69-115.  consume: x = F^-1 X, kx = F^-1 (eK X), dx = D x, then the u, y, w, z
-// updates; produce: transform inputs (u - w/t) + D^T((y1+y2) - (z1+z2)/t) and y0 - z0/t.
-template <typename T>
-struct AdmmArgs {
-    RowCommon<T> c;
-    T* u; T* w; T* y0; T* y1; T* y2; T* z0; T* z1; T* z2;
-    const T* b;
-    T* sol;  // when non-null the consume step stores x (the look-ahead solution of admm:118-132)
-    T t, it, rho, omr, itg, l2div;  // it = 1/t, omr = 1 - rho, itg = gamma/t, l2div = 2/t + 1
-    int objective;
-    int sol_only;  // consume computes x and the loss only (final solve, admm:160-173)
-};
-
-template <typename T, int V, int NG, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_admm_row(AdmmArgs<T> a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const RowCommon<T>& c = a.c;
-    const int tid = threadIdx.x, nt = blockDim.x, W = c.W;
-    RowLds<T> L(smem, W);
-    load_table(L.tw, c.twW, W, tid, nt);
-    const bool spec = c.eDrow != nullptr;
-    const int nrows = c.batch * c.H;
-    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const int plane = row / c.H;
-        if (c.stop && c.stop[plane] >= 0) continue;
-        const size_t ro = (size_t)row * W, so = (size_t)row * c.Wp;
-        T x[NG][V], kx[NG][V], dx[NG][V];
-        __syncthreads();
-        if (c.do_consume) {
-            if (spec && !a.sol_only) {
-                row_spectral_D(L, c, c.S0 + so, tid, nt);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const int j = (tid + g * nt) * V;
-                    if (j < W) {
-#pragma unroll
-                        for (int v = 0; v < V; ++v) dx[g][v] = L.data[SW(j + v)].x;
-                    }
-                }
-                __syncthreads();
-            }
-            row_pack(L.data, c.fw, W, c.S0 + so, c.S1 + so, tid, nt);
-            __syncthreads();
-            fft_inverse<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int j = (tid + g * nt) * V;
-                if (j < W) {
-                    T prev = L.data[SW(j == 0 ? W - 1 : j - 1)].x;
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const cx<T> e = L.data[SW(j + v)];
-                        x[g][v] = e.x;
-                        kx[g][v] = e.y;
-                        if (!spec) dx[g][v] = e.x - prev;
-                        prev = e.x;
-                    }
-                }
-            }
-        }
-        T pb[NG][V], qin[NG][V], sv[NG][V];
-        double acc[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int j = (tid + g * nt) * V;
-            if (j < W) {
-                T b[V];
-                vload<T, V>(a.b + ro + j, b);
-                if (c.do_consume) {
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const T d = x[g][v] - b[v];
-                        acc[0] += (double)t_abs(d); acc[1] += (double)d * (double)d;
-                    }
-                    if (a.sol) vstore<T, V>(a.sol + ro + j, x[g]);
-                }
-                if (a.sol_only) continue;
-                T u[V], w[V], y0[V], y1[V], y2[V], z0[V], z1[V], z2[V];
-                vload<T, V>(a.u + ro + j, u);
-                vload<T, V>(a.w + ro + j, w);
-                vload<T, V>(a.y0 + ro + j, y0);
-                vload<T, V>(a.y1 + ro + j, y1);
-                vload<T, V>(a.y2 + ro + j, y2);
-                vload<T, V>(a.z0 + ro + j, z0);
-                vload<T, V>(a.z1 + ro + j, z1);
-                vload<T, V>(a.z2 + ro + j, z2);
-                if (c.do_consume) {
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const T un = clip01(a.rho * x[g][v] + a.omr * u[v] + a.it * w[v]);
-                        const T pp0 = a.rho * kx[g][v] + a.omr * y0[v] + a.it * z0[v];
-                        const T pp1 = a.rho * dx[g][v] + a.omr * y1[v] + a.it * z1[v];
-                        const T pp2 = a.rho * dx[g][v] + a.omr * y2[v] + a.it * z2[v];
-                        T y0n, y1n, y2n;
-                        if (a.objective == 0) y0n = b[v] + soft(pp0 - b[v], a.it); else y0n = b[v] + (pp0 - b[v]) / a.l2div;
-                        iso(pp1, pp2, a.itg, y1n, y2n);
-                        w[v] = w[v] + a.t * (x[g][v] - un);
-                        z0[v] = z0[v] + a.t * (kx[g][v] - y0n);
-                        z1[v] = z1[v] + a.t * (dx[g][v] - y1n);
-                        z2[v] = z2[v] + a.t * (dx[g][v] - y2n);
-                        u[v] = un; y0[v] = y0n; y1[v] = y1n; y2[v] = y2n;
-                    }
-                    vstore<T, V>(a.u + ro + j, u);
-                    vstore<T, V>(a.w + ro + j, w);
-                    vstore<T, V>(a.y0 + ro + j, y0);
-                    vstore<T, V>(a.y1 + ro + j, y1);
-                    vstore<T, V>(a.y2 + ro + j, y2);
-                    vstore<T, V>(a.z0 + ro + j, z0);
-                    vstore<T, V>(a.z1 + ro + j, z1);
-                    vstore<T, V>(a.z2 + ro + j, z2);
-                }
-                if (c.do_produce) {
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        pb[g][v] = u[v] - a.it * w[v];
-                        qin[g][v] = y0[v] - a.it * z0[v];
-                        sv[g][v] = (y1[v] + y2[v]) - a.it * (z1[v] + z2[v]);
-                    }
-                    L.edge[tid + g * nt] = sv[g][0];
-                }
-            }
-        }
-        if (c.do_consume) {
-            block_reduce<4>(acc, L.red, tid, nt);
-            if (tid == 0) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) c.partials[(size_t)row * 4 + s] = acc[s];
-            }
-        }
-        __syncthreads();
-        if (c.do_produce && !a.sol_only) {
-            if (spec) {
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const int j = (tid + g * nt) * V;
-                    if (j < W) {
-#pragma unroll
-                        for (int v = 0; v < V; ++v) L.data[SW(j + v)] = mk<T>(sv[g][v], 0);
-                    }
-                }
-                __syncthreads();
-                fft_forward<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
-                row_unpack<T>(L.data, c.fw, W, c.S0 + so, nullptr, c.eDrow, false, tid, nt);
-                __syncthreads();
-            }
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int j = (tid + g * nt) * V;
-                if (j < W) {
-                    const int grp = tid + g * nt;
-                    const T snext = L.edge[grp + 1 == c.V_groups ? 0 : grp + 1];
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const T nx = (v + 1 < V) ? sv[g][(v + 1) % V] : snext;
-                        const T re = spec ? pb[g][v] : pb[g][v] + (sv[g][v] - nx);
-                        L.data[SW(j + v)] = mk<T>(re, qin[g][v]);
-                    }
-                }
-            }
-            __syncthreads();
-            fft_forward<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
-            row_unpack<T>(L.data, c.fw, W, c.S0 + so, c.S1 + so, nullptr, spec, tid, nt);
-        }
-    }
-}
-
-// ------------------------------------------------------------------ Chambolle-Pock row kernels
+// ------------------------------------------------------------------ Chambolle-Pock row kernel
 // chambolle_pock/algorithm.py:58-92.  A workgroup owns two image rows (the two real slots of the
-// complex transform).  STEP 0 ("dual"): consume Kz, update y (cp:60-76), produce the transform input
-// y0.  STEP 1 ("primal"): consume K^T y0, update x and z (cp:79-87), produce the transform input z.
-// With row-spectral D the dual step also needs D z and the primal step D^T(y1+y2) in the row
-// spectrum; those use one extra transform each.
+// complex transform).  step 0 ("dual"): consume K z, update y (cp:60-76), produce the transform
+// input y0.  step 1 ("primal"): consume K^T y0, update x and z (cp:79-87), produce the transform
+// input z.  D z and D^T (y1 + y2) are 2-tap stencils read straight from the (read-only in that
+// step) arrays; with SPEC they are row-spectral: the dual step spends one extra transform pair on
+// D z and leaves conj(eD) F_row(y1 + y2) / W in S1, which the primal step adds before its inverse.
 template <typename T>
 struct CpArgs {
-    RowCommon<T> c;
-    T* x; T* z; T* y0; T* y1; T* y2;
+    T* __restrict__ x; T* __restrict__ z; T* __restrict__ y0; T* __restrict__ y1; T* __restrict__ y2;
     const T* b;
     T t, s, is, isg, l2div;  // is = 1/s, isg = gamma/s, l2div = 2/s + 1
     int objective;
     int step;
 };
 
-template <typename T, int V, int NG, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_cp_row(CpArgs<T> a) {
+template <typename T, int V, int NG, bool SPEC, int WF, int MAXT, int MINW>
+__global__ void __launch_bounds__(MAXT, MINW) k_cp_row(RowCommon<T> c, CpArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const RowCommon<T>& c = a.c;
     const int tid = threadIdx.x, nt = blockDim.x, W = c.W, H = c.H;
     RowLds<T> L(smem, W);
-    load_table(L.tw, c.twW, W, tid, nt);
-    const bool spec = c.eDrow != nullptr;
+    const Tw<T> tw = tw_setup(L.tw, c.twW, W, tid, nt);
     const int ppp = (H + 1) >> 1;  // row pairs per image
     const int npairs = c.batch * ppp;
+    constexpr int NH = SPEC ? NG : 1;
+    constexpr int KP = (V * NG) / 2 + 1;
     for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const int plane = pr / ppp;
-        if (c.stop && c.stop[plane] >= 0) continue;
         const int r0 = (pr - plane * ppp) * 2;
         const int nslot = (r0 + 1 < H) ? 2 : 1;
         const size_t row0 = (size_t)plane * H + r0;
-        T in[2][NG][V];  // consumed transform output per slot
-        T aux[2][NG][V]; // row-spectral D z (dual step)
+        const SpecRow sa = spec_row(c.lay, plane, r0), sb = spec_row(c.lay, plane, r0 + (nslot - 1));
+        T aux[2][NH][V];  // row-spectral D z (dual step, SPEC)
         __syncthreads();
         if (c.do_consume) {
-            if (spec && a.step == 0) {
-                // D z for both rows: transform z rows, multiply by eD, inverse
+            if (SPEC && a.step == 0) {
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int j = (tid + g * nt) * V;
@@ -884,14 +886,13 @@ __global__ void __launch_bounds__(MAXT) k_cp_row(CpArgs<T> a) {
                     }
                 }
                 __syncthreads();
-                fft_forward<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
-                // multiply the two separated spectra by eD and repack in place: since eD is applied to
-                // both slots alike, Z' [k] = eD[k] Z[k] for k <= W/2 and conj-mirrored table above.
+                fft_fwd<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
                 {
+                    // both slots are multiplied by the Hermitian-extended eD: Z'[k] = eD[k] Z[k], Z'[W-k] = conj(eD[k]) Z[W-k]
                     const int half = W >> 1;
                     for (int k = tid; k <= half; k += nt) {
                         const int km = (k == 0) ? 0 : W - k;
-                        const int p1 = SW(pos_of_freq(c.fw, k)), p2 = SW(pos_of_freq(c.fw, km));
+                        const int p1 = SW(pos_freq<WF>(c.fw, k)), p2 = SW(pos_freq<WF>(c.fw, km));
                         const cx<T> e = c.eDrow[k];
                         const cx<T> Z1 = L.data[p1], Z2 = L.data[p2];
                         L.data[p1] = Z1 * e;
@@ -899,7 +900,7 @@ __global__ void __launch_bounds__(MAXT) k_cp_row(CpArgs<T> a) {
                     }
                 }
                 __syncthreads();
-                fft_inverse<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
+                fft_inv<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
                 const T sc = (T)1 / (T)W;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
@@ -908,81 +909,76 @@ __global__ void __launch_bounds__(MAXT) k_cp_row(CpArgs<T> a) {
 #pragma unroll
                         for (int v = 0; v < V; ++v) {
                             const cx<T> e = L.data[SW(j + v)];
-                            aux[0][g][v] = e.x * sc;
-                            aux[1][g][v] = e.y * sc;
+                            aux[0][g % NH][v] = e.x * sc;
+                            aux[1][g % NH][v] = e.y * sc;
                         }
                     }
                 }
                 __syncthreads();
             }
-            const bool addS1 = spec && a.step == 1;
-            row_pack(L.data, c.fw, W, c.S0 + row0 * c.Wp, nslot == 2 ? c.S0 + (row0 + 1) * c.Wp : nullptr, tid, nt,
-                     addS1 ? c.S1 + row0 * c.Wp : nullptr, (addS1 && nslot == 2) ? c.S1 + (row0 + 1) * c.Wp : nullptr);
+            const bool addS1 = SPEC && a.step == 1;
+            row_pack<T, KP, WF>(L.data, c.fw, W, c.S0, sa, nslot == 2 ? c.S0 : (const cx<T>*)nullptr, sb, tid, nt, addS1 ? c.S1 : (const cx<T>*)nullptr, (addS1 && nslot == 2) ? c.S1 : (const cx<T>*)nullptr);
             __syncthreads();
-            fft_inverse<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
+            fft_inv<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+        }
+        double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int j = (tid + g * nt) * V;
-                if (j < W) {
+        for (int g = 0; g < NG; ++g) {
+            const int j = (tid + g * nt) * V;
+            if (j < W) {
+                T in[2][V], out[2][V];
+                if (c.do_consume) {
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
                         const cx<T> e = L.data[SW(j + v)];
-                        in[0][g][v] = e.x;
-                        in[1][g][v] = e.y;
+                        in[0][v] = e.x;
+                        in[1][v] = e.y;
                     }
                 }
-            }
-        }
-        T out[2][NG][V];
-        double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            if (sl < nslot) {
-                const size_t ro = (row0 + sl) * W;
+                for (int sl = 0; sl < 2; ++sl) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const int j = (tid + g * nt) * V;
-                    if (j < W) {
+                    for (int v = 0; v < V; ++v) out[sl][v] = (T)0;
+                    if (sl < nslot) {
+                        const size_t ro = (row0 + sl) * W;
                         if (a.step == 0) {
-                            // dual step
                             T z[V], y0[V], y1[V], y2[V], b[V];
                             vload<T, V>(a.z + ro + j, z);
                             vload<T, V>(a.y0 + ro + j, y0);
                             vload<T, V>(a.y1 + ro + j, y1);
                             vload<T, V>(a.y2 + ro + j, y2);
                             vload<T, V>(a.b + ro + j, b);
-                            T prev = a.z[ro + (j == 0 ? W - 1 : j - 1)];
+                            T prev = SPEC ? (T)0 : a.z[ro + (j == 0 ? W - 1 : j - 1)];
 #pragma unroll
                             for (int v = 0; v < V; ++v) {
-                                const T dz = spec ? aux[sl][g][v] : z[v] - prev;
+                                const T dz = SPEC ? aux[sl][g % NH][v] : z[v] - prev;             // cp:61
                                 prev = z[v];
-                                const T g0 = y0[v] + a.s * in[sl][g][v];
+                                const T g0 = y0[v] + a.s * in[sl][v];                             // cp:66
                                 const T g1 = y1[v] + a.s * dz;
                                 const T g2 = y2[v] + a.s * dz;
                                 T pr0;
-                                if (a.objective == 0) pr0 = soft(g0 / a.s - b[v], a.is); else pr0 = (g0 / a.s - b[v]) / a.l2div;
+                                if (a.objective == 0) pr0 = soft(g0 / a.s - b[v], a.is); else pr0 = (g0 / a.s - b[v]) / a.l2div;  // cp:69-72
                                 y0[v] = g0 - a.s * b[v] - a.s * pr0;
                                 T i1, i2;
-                                iso(g1 / a.s, g2 / a.s, a.isg, i1, i2);
+                                iso(g1 / a.s, g2 / a.s, a.isg, i1, i2);                           // cp:75
                                 y1[v] = g1 - a.s * i1;
                                 y2[v] = g2 - a.s * i2;
-                                out[sl][g][v] = y0[v];
+                                out[sl][v] = y0[v];
                             }
                             vstore<T, V>(a.y0 + ro + j, y0);
                             vstore<T, V>(a.y1 + ro + j, y1);
                             vstore<T, V>(a.y2 + ro + j, y2);
                         } else {
-                            // primal step
                             T z[V];
                             if (c.do_consume) {
-                                T x[V], y1[V], y2[V], b[V];
+                                T x[V], b[V], dty[V];
                                 vload<T, V>(a.x + ro + j, x);
                                 vload<T, V>(a.b + ro + j, b);
-                                T dty[V];
-                                if (spec) {
+                                if (SPEC) {
 #pragma unroll
-                                    for (int v = 0; v < V; ++v) dty[v] = 0;  // included spectrally in `in`
+                                    for (int v = 0; v < V; ++v) dty[v] = (T)0;  // already inside `in` (added in the row spectrum)
                                 } else {
+                                    T y1[V], y2[V];
                                     vload<T, V>(a.y1 + ro + j, y1);
                                     vload<T, V>(a.y2 + ro + j, y2);
                                     const int jn = (j + V == W) ? 0 : j + V;
@@ -991,16 +987,16 @@ __global__ void __launch_bounds__(MAXT) k_cp_row(CpArgs<T> a) {
                                     for (int v = 0; v < V; ++v) {
                                         const T sc = y1[v] + y2[v];
                                         const T sn = (v + 1 < V) ? (y1[(v + 1) % V] + y2[(v + 1) % V]) : snext;
-                                        dty[v] = sc - sn;
+                                        dty[v] = sc - sn;                                         // D^T(y1 + y2), cp:79
                                     }
                                 }
 #pragma unroll
                                 for (int v = 0; v < V; ++v) {
-                                    const T aty = in[sl][g][v] + dty[v];
-                                    const T xn = clip01(x[v] - a.t * aty);
-                                    z[v] = (T)2 * xn - x[v];
+                                    const T aty = in[sl][v] + dty[v];
+                                    const T xn = clip01(x[v] - a.t * aty);                        // cp:83-86
+                                    z[v] = (T)2 * xn - x[v];                                      // cp:87
                                     x[v] = xn;
-                                    const T d = xn - b[v];
+                                    const T d = xn - b[v];                                        // cp:96
                                     acc[sl][0] += (double)t_abs(d); acc[sl][1] += (double)d * (double)d;
                                 }
                                 vstore<T, V>(a.x + ro + j, x);
@@ -1009,9 +1005,13 @@ __global__ void __launch_bounds__(MAXT) k_cp_row(CpArgs<T> a) {
                                 vload<T, V>(a.z + ro + j, z);
                             }
 #pragma unroll
-                            for (int v = 0; v < V; ++v) out[sl][g][v] = z[v];
+                            for (int v = 0; v < V; ++v) out[sl][v] = z[v];
                         }
                     }
+                }
+                if (c.do_produce) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) L.data[SW(j + v)] = mk<T>(out[0][v], out[1][v]);
                 }
             }
         }
@@ -1019,30 +1019,19 @@ __global__ void __launch_bounds__(MAXT) k_cp_row(CpArgs<T> a) {
             double accs[4];
             for (int sl = 0; sl < 2; ++sl) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) accs[s] = acc[sl][s];
+                for (int q = 0; q < 4; ++q) accs[q] = acc[sl][q];
                 block_reduce<4>(accs, L.red, tid, nt);
                 if (tid == 0 && sl < nslot) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) c.partials[(row0 + sl) * 4 + s] = accs[s];
+                    for (int q = 0; q < 4; ++q) c.partials[(row0 + sl) * 4 + q] = accs[q];
                 }
             }
         }
         __syncthreads();
         if (c.do_produce) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int j = (tid + g * nt) * V;
-                if (j < W) {
-#pragma unroll
-                    for (int v = 0; v < V; ++v) L.data[SW(j + v)] = mk<T>(out[0][g][v], nslot == 2 ? out[1][g][v] : (T)0);
-                }
-            }
-            __syncthreads();
-            fft_forward<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
-            row_unpack<T>(L.data, c.fw, W, c.S0 + row0 * c.Wp, nslot == 2 ? c.S0 + (row0 + 1) * c.Wp : nullptr, nullptr, false, tid, nt);
-            if (spec && a.step == 0) {
-                // second output of the dual step: row spectrum of (y1 + y2) times conj(eD), into S1;
-                // the column kernel leaves S1 alone and the primal step adds its inverse row transform.
+            fft_fwd<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+            row_unpack<T, WF>(L.data, c.fw, W, c.S0, sa, nslot == 2 ? c.S0 : nullptr, sb, nullptr, false, tid, nt);
+            if (SPEC && a.step == 0) {
                 __syncthreads();
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
@@ -1060,18 +1049,16 @@ __global__ void __launch_bounds__(MAXT) k_cp_row(CpArgs<T> a) {
                     }
                 }
                 __syncthreads();
-                fft_forward<T>(L.data, 1, 0, L.tw, c.fw, 0, tid, nt);
+                fft_fwd<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
                 {
                     const int half = W >> 1;
+                    const T hw = (T)0.5 / (T)W;  // 1/W: this spectrum skips the normalised column stage
                     for (int k = tid; k <= half; k += nt) {
                         const int km = (k == 0) ? 0 : W - k;
-                        const cx<T> Z1 = L.data[SW(pos_of_freq(c.fw, k))], Z2 = L.data[SW(pos_of_freq(c.fw, km))];
+                        const cx<T> Z1 = L.data[SW(pos_freq<WF>(c.fw, k))], Z2 = L.data[SW(pos_freq<WF>(c.fw, km))];
                         const cx<T> e = c.eDrow[k];
-                        const T hw = (T)0.5 / (T)W;  // 1/W: this spectrum skips the normalised column stage
-                        const cx<T> A = mulc(mk<T>(hw * (Z1.x + Z2.x), hw * (Z1.y - Z2.y)), e);
-                        const cx<T> B = mulc(mk<T>(hw * (Z1.y + Z2.y), hw * (Z2.x - Z1.x)), e);
-                        c.S1[row0 * c.Wp + k] = A;
-                        if (nslot == 2) c.S1[(row0 + 1) * c.Wp + k] = B;
+                        c.S1[sa.at(k)] = mulc(mk<T>(hw * (Z1.x + Z2.x), hw * (Z1.y - Z2.y)), e);
+                        if (nslot == 2) c.S1[sb.at(k)] = mulc(mk<T>(hw * (Z1.y + Z2.y), hw * (Z2.x - Z1.x)), e);
                     }
                 }
             }
@@ -1082,14 +1069,14 @@ __global__ void __launch_bounds__(MAXT) k_cp_row(CpArgs<T> a) {
 // ------------------------------------------------------------ plain row transforms (row pairs)
 template <typename T>
 struct PlainRowArgs {
-    int H, W, Wp, batch;
+    int H, W, batch;
     FftDesc fw;
+    SpecLayout lay;
     const cx<T>* twW;
-    cx<T>* S;       // half-row-spectra [batch][H][Wp]
+    cx<T>* S;       // half-row-spectra, tiled layout
     const T* src;   // real -> spectrum
     T* dst;         // spectrum -> real
     T scale;        // applied to the real output
-    const T* add;   // optional: dst = scale * result + add
 };
 
 template <typename T>
@@ -1097,17 +1084,18 @@ __global__ void __launch_bounds__(1024) k_rows_r2c(PlainRowArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, W = a.W, H = a.H;
     RowLds<T> L(smem, W);
-    load_table(L.tw, a.twW, W, tid, nt);
+    const Tw<T> tw = tw_setup(L.tw, a.twW, W, tid, nt);
     const int ppp = (H + 1) >> 1, npairs = a.batch * ppp;
     for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const int plane = pr / ppp, r0 = (pr - plane * ppp) * 2;
         const bool two = r0 + 1 < H;
         const size_t row0 = (size_t)plane * H + r0;
+        const SpecRow sa = spec_row(a.lay, plane, r0), sb = spec_row(a.lay, plane, two ? r0 + 1 : r0);
         __syncthreads();
         for (int j = tid; j < W; j += nt) L.data[SW(j)] = mk<T>(a.src[row0 * W + j], two ? a.src[(row0 + 1) * W + j] : (T)0);
         __syncthreads();
-        fft_forward<T>(L.data, 1, 0, L.tw, a.fw, 0, tid, nt);
-        row_unpack<T>(L.data, a.fw, W, a.S + row0 * a.Wp, two ? a.S + (row0 + 1) * a.Wp : nullptr, nullptr, false, tid, nt);
+        fft_forward<T>(L.data, 1, 0, tw, a.fw, 0, tid, nt);
+        row_unpack<T>(L.data, a.fw, W, a.S, sa, two ? a.S : nullptr, sb, nullptr, false, tid, nt);
     }
 }
 
@@ -1116,25 +1104,21 @@ __global__ void __launch_bounds__(1024) k_rows_c2r(PlainRowArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, W = a.W, H = a.H;
     RowLds<T> L(smem, W);
-    load_table(L.tw, a.twW, W, tid, nt);
+    const Tw<T> tw = tw_setup(L.tw, a.twW, W, tid, nt);
     const int ppp = (H + 1) >> 1, npairs = a.batch * ppp;
     for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const int plane = pr / ppp, r0 = (pr - plane * ppp) * 2;
         const bool two = r0 + 1 < H;
         const size_t row0 = (size_t)plane * H + r0;
+        const SpecRow sa = spec_row(a.lay, plane, r0), sb = spec_row(a.lay, plane, two ? r0 + 1 : r0);
         __syncthreads();
-        row_pack(L.data, a.fw, W, a.S + row0 * a.Wp, two ? a.S + (row0 + 1) * a.Wp : nullptr, tid, nt);
+        row_pack<T, 5>(L.data, a.fw, W, a.S, sa, two ? a.S : (const cx<T>*)nullptr, sb, tid, nt);
         __syncthreads();
-        fft_inverse<T>(L.data, 1, 0, L.tw, a.fw, 0, tid, nt);
+        fft_inverse<T>(L.data, 1, 0, tw, a.fw, 0, tid, nt);
         for (int j = tid; j < W; j += nt) {
             const cx<T> e = L.data[SW(j)];
-            T v0 = e.x * a.scale, v1 = e.y * a.scale;
-            if (a.add) {
-                v0 += a.add[row0 * W + j];
-                if (two) v1 += a.add[(row0 + 1) * W + j];
-            }
-            a.dst[row0 * W + j] = v0;
-            if (two) a.dst[(row0 + 1) * W + j] = v1;
+            a.dst[row0 * W + j] = e.x * a.scale;
+            if (two) a.dst[(row0 + 1) * W + j] = e.y * a.scale;
         }
     }
 }
@@ -1189,7 +1173,7 @@ __global__ void k_reduce_partial(const T* x, const T* y, size_t n_per_image, int
         partial[blockIdx.x * 2 + 1] = v[1];
     }
 }
-__global__ void k_reduce_final(const double* partial, int chunks, double npix, double* out4) {
+static __global__ void k_reduce_final(const double* partial, int chunks, double npix, double* out4) {
     const int image = blockIdx.x;
     if (threadIdx.x == 0) {
         double s1 = 0, s2 = 0;
@@ -1224,7 +1208,7 @@ __device__ __forceinline__ int colfreq_of_pos(const ColMap& m, int r) {
 // Hermitian-symmetrise in double, optionally take the reciprocal first, scale, keep k2 <= W/2 and
 // store rows in column-transform position order.  TI = float or double component type of the input.
 template <typename T, typename TI>
-__global__ void k_import_mult(const cx<TI>* in, cx<T>* out, T* out_real, int H, int W, int Wh, int Wp, ColMap cm, int recip, int conj_in, double scale) {
+__global__ void k_import_mult(const cx<TI>* in, cx<T>* out, T* out_real, int H, int W, int Wh, SpecLayout lay, ColMap cm, int recip, int conj_in, double scale) {
     const size_t total = (size_t)H * Wh;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / Wh), k2 = (int)(i - (size_t)r * Wh);
@@ -1238,56 +1222,59 @@ __global__ void k_import_mult(const cx<TI>* in, cx<T>* out, T* out_real, int H, 
         }
         if (conj_in) { ay = -ay; by = -by; }
         const double rx = 0.5 * (ax + bx) * scale, ry = 0.5 * (ay - by) * scale;
-        if (out) out[(size_t)r * Wp + k2] = mk<T>((T)rx, (T)ry);
-        if (out_real) out_real[(size_t)r * Wp + k2] = (T)rx;
+        const size_t o = spec_row(lay, 0, r).at(k2);
+        if (out) out[o] = mk<T>((T)rx, (T)ry);
+        if (out_real) out_real[o] = (T)rx;
     }
 }
 
 // G[r][k2] = scale / (1 + cK |eK|^2 + cD ed2[k2])  (mm:67-72 in real arithmetic)
 template <typename T>
-__global__ void k_make_G(const cx<T>* eK, const T* ed2, T* G, int H, int Wh, int Wp, T cK, T cD, T scale) {
+__global__ void k_make_G(const cx<T>* eK, const T* ed2, T* G, int H, int Wh, SpecLayout lay, T cK, T cD, T scale) {
     const size_t total = (size_t)H * Wh;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / Wh), k2 = (int)(i - (size_t)r * Wh);
-        const cx<T> e = eK[(size_t)r * Wp + k2];
-        G[(size_t)r * Wp + k2] = scale / ((T)1 + cK * (e.x * e.x + e.y * e.y) + cD * ed2[k2]);
+        const size_t o = spec_row(lay, 0, r).at(k2);
+        const cx<T> e = eK[o];
+        G[o] = scale / ((T)1 + cK * (e.x * e.x + e.y * e.y) + cD * ed2[k2]);
     }
 }
 // mult[r][k2] = 1 + |eK|^2 + 2 ed2  (apply_Mat, mm:106-108)
 template <typename T>
-__global__ void k_make_mat(const cx<T>* eK, const T* ed2, cx<T>* out, int H, int Wh, int Wp) {
+__global__ void k_make_mat(const cx<T>* eK, const T* ed2, cx<T>* out, int H, int Wh, SpecLayout lay) {
     const size_t total = (size_t)H * Wh;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / Wh), k2 = (int)(i - (size_t)r * Wh);
-        const cx<T> e = eK[(size_t)r * Wp + k2];
-        out[(size_t)r * Wp + k2] = mk<T>((T)1 + (e.x * e.x + e.y * e.y) + (T)2 * ed2[k2], (T)0);
+        const size_t o = spec_row(lay, 0, r).at(k2);
+        const cx<T> e = eK[o];
+        out[o] = mk<T>((T)1 + (e.x * e.x + e.y * e.y) + (T)2 * ed2[k2], (T)0);
     }
 }
 // broadcast a row table to every row: out[r][k2] = tab[k2]
 template <typename T>
-__global__ void k_bcast_row(const cx<T>* tab, cx<T>* out, int H, int Wh, int Wp) {
+__global__ void k_bcast_row(const cx<T>* tab, cx<T>* out, int H, int Wh, SpecLayout lay) {
     const size_t total = (size_t)H * Wh;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / Wh), k2 = (int)(i - (size_t)r * Wh);
-        out[(size_t)r * Wp + k2] = tab[k2];
+        out[spec_row(lay, 0, r).at(k2)] = tab[k2];
     }
 }
 
 // Export a half-plane, position-ordered multiplier to the reference's full natural layout.
 template <typename T>
-__global__ void k_export_full(const cx<T>* half, cx<T>* out, int H, int W, int Wp, ColMap cm) {
+__global__ void k_export_full(const cx<T>* half, cx<T>* out, int H, int W, SpecLayout lay, ColMap cm) {
     const size_t total = (size_t)H * W;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k1 = (int)(i / W), k2 = (int)(i - (size_t)k1 * W);
         if (k2 <= W / 2) {
-            out[i] = half[(size_t)colpos_of_freq(cm, k1) * Wp + k2];
+            out[i] = half[spec_row(lay, 0, colpos_of_freq(cm, k1)).at(k2)];
         } else {
             const int m1 = k1 == 0 ? 0 : H - k1;
-            out[i] = cconj(half[(size_t)colpos_of_freq(cm, m1) * Wp + (W - k2)]);
+            out[i] = cconj(half[spec_row(lay, 0, colpos_of_freq(cm, m1)).at(W - k2)]);
         }
     }
 }
 
-__global__ void k_iters_done(const int* stop, int* out, int n, int n_iters) {
+static __global__ void k_iters_done(const int* stop, int* out, int n, int n_iters) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = stop[i] >= 0 ? stop[i] : n_iters;
 }

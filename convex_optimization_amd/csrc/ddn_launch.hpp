@@ -1,0 +1,104 @@
+// Shared host-side helpers of libddn's translation units: error string, HIP error check, the
+// dynamic-LDS attribute, and the launchers of the fused row kernels.  The row kernels are explicitly
+// instantiated in ddn_row_<solver>_<dtype>.hip (one translation unit each, compiled in parallel);
+// ddn_api.hip only references them through `extern template` declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <set>
+#include <string>
+
+#include "../../include/ddn.h"
+#include "ddn_kernels.hpp"
+
+inline std::string& ddn_err() {
+    thread_local std::string e;
+    return e;
+}
+inline int fail(int code, const std::string& msg) {
+    ddn_err() = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(DDN_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr size_t kLdsMax = 160 * 1024;
+
+inline int ensure_lds_attr(const void* fn) {
+    static std::mutex mu;
+    static std::set<const void*> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count(fn)) return DDN_OK;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+    done.insert(fn);
+    return DDN_OK;
+}
+
+template <typename K, typename C_, typename A_>
+int launch_row_fn(hipStream_t st, K fn, int grid, int threads, size_t lds, const C_& c, const A_& a) {
+    int rc = ensure_lds_attr((const void*)fn);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, st, c, a);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+// V = 4: 16-byte accesses, four pixel groups per thread, 256-thread workgroups, four per CU
+// (two with row-spectral D, which holds more state).  V = 1: any W up to 8192, scalar accesses.
+// V = 4: 16-byte accesses, four pixel groups per thread, 256-thread workgroups, two per CU.  Float
+// kernels for W = 512 / 1024 / 2048 / 4096 use the compile-time specialised transform and hold the
+// whole row's global loads in registers (PF).  V = 1: any W up to 8192, scalar accesses.
+template <typename T, class P, int WF>
+int row_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCommon<T>& c, const typename P::Args& a) {
+    return launch_row_fn(st, k_solver_row<T, P, 4, 4, false, 1, WF, 256, 2>, grid, threads, lds, c, a);
+}
+
+template <typename T, class P>
+int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const RowCommon<T>& c, const typename P::Args& a) {
+    const bool spec = c.eDrow != nullptr;
+    if (V == 4) {
+        if (spec) return launch_row_fn(st, k_solver_row<T, P, 4, 4, true, 0, 0, 256, 2>, grid, threads, lds, c, a);
+        if constexpr (sizeof(T) == 4) {
+            switch (c.W) {
+                case 512: return row_launch_w<T, P, 512>(st, grid, threads, lds, c, a);
+                case 1024: return row_launch_w<T, P, 1024>(st, grid, threads, lds, c, a);
+                case 2048: return row_launch_w<T, P, 2048>(st, grid, threads, lds, c, a);
+                case 4096: return row_launch_w<T, P, 4096>(st, grid, threads, lds, c, a);
+                default: break;
+            }
+        }
+        return launch_row_fn(st, k_solver_row<T, P, 4, 4, false, 0, 0, 256, 2>, grid, threads, lds, c, a);
+    }
+    if (spec) return launch_row_fn(st, k_solver_row<T, P, 1, 8, true, 0, 0, 1024, 1>, grid, threads, lds, c, a);
+    return launch_row_fn(st, k_solver_row<T, P, 1, 8, false, 0, 0, 1024, 1>, grid, threads, lds, c, a);
+}
+
+template <typename T, int WF>
+int cp_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCommon<T>& c, const CpArgs<T>& a) {
+    return launch_row_fn(st, k_cp_row<T, 4, 4, false, WF, 256, 2>, grid, threads, lds, c, a);
+}
+
+template <typename T>
+int cp_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const RowCommon<T>& c, const CpArgs<T>& a) {
+    const bool spec = c.eDrow != nullptr;
+    if (V == 4) {
+        if (spec) return launch_row_fn(st, k_cp_row<T, 4, 4, true, 0, 256, 2>, grid, threads, lds, c, a);
+        if constexpr (sizeof(T) == 4) {
+            switch (c.W) {
+                case 512: return cp_launch_w<T, 512>(st, grid, threads, lds, c, a);
+                case 1024: return cp_launch_w<T, 1024>(st, grid, threads, lds, c, a);
+                case 2048: return cp_launch_w<T, 2048>(st, grid, threads, lds, c, a);
+                case 4096: return cp_launch_w<T, 4096>(st, grid, threads, lds, c, a);
+                default: break;
+            }
+        }
+        return launch_row_fn(st, k_cp_row<T, 4, 4, false, 0, 256, 2>, grid, threads, lds, c, a);
+    }
+    if (spec) return launch_row_fn(st, k_cp_row<T, 1, 8, true, 0, 1024, 1>, grid, threads, lds, c, a);
+    return launch_row_fn(st, k_cp_row<T, 1, 8, false, 0, 1024, 1>, grid, threads, lds, c, a);
+}

@@ -75,4 +75,4 @@ def check(rc: int):
 EXPORTED = ["ddn_version", "ddn_last_error", "ddn_plan_create", "ddn_plan_destroy", "ddn_plan_set_stream", "ddn_plan_tune",
             "ddn_plan_set_kernel", "ddn_plan_set_eig", "ddn_plan_set_resolvent", "ddn_plan_get_eigK", "ddn_apply",
             "ddn_apply_multiplier", "ddn_circular_convolve2d", "ddn_prox", "ddn_reduce", "ddn_cp_run", "ddn_admm_run",
-            "ddn_pdr_run", "ddn_pddr_run", "ddn_plan_last_timing", "ddn_plan_enable_timing"]
+            "ddn_pdr_run", "ddn_pddr_run", "ddn_plan_last_timing", "ddn_plan_enable_timing", "ddn_plan_debug_stamps"]

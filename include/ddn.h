@@ -82,7 +82,7 @@ int ddn_plan_set_stream(ddn_plan* p, void* stream);
 
 /* Column-stage tiling knobs (0 = heuristic): number of columns per workgroup and the
  * split H = A x B of the column transform (A = 1: one pass).  For experiments. */
-int ddn_plan_tune(ddn_plan* p, int cols_per_block, int split_A, int row_threads);
+int ddn_plan_tune(ddn_plan* p, int cols_per_block, int split_A, int col_threads);
 
 /* Replaces eig_vals_for_periodic_conv_op (eig_vals_for_periodic_conv_op.py:5-61) and
  * setup_operators (mm:48-72): builds, on the device, the eigenvalue array of the
@@ -173,6 +173,11 @@ int ddn_pddr_run(ddn_plan* p, void* p_dev, void* q_dev, const void* b_dev,
  * row kernel) and of all its kernels; synchronises the stream. */
 int ddn_plan_last_timing(ddn_plan* p, double* row_kernel_ms_avg, double* col_kernel_ms_avg, int* n_row_launches, int* n_col_launches);
 int ddn_plan_enable_timing(ddn_plan* p, int on);
+
+/* Diagnostic (no counterpart in the reference): when the environment variable DDN_DEBUG_STAMPS=1 was
+ * set at plan creation, copies the clock stamps the fused row kernel took at its phase boundaries in
+ * its last launch (16 int64 per workgroup, first n_wg workgroups) to host memory. */
+int ddn_plan_debug_stamps(ddn_plan* p, long long* out_host, int n_wg);
 
 #ifdef __cplusplus
 }

@@ -428,7 +428,10 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc) {
     const int W = p->W;
     if (aligned && W % 4 == 0 && W <= 4096) {
         rc.V = 4;
-        rc.threads = std::min(256, std::max(64, (W / 16 + 63) / 64 * 64));
+        // float kernels specialised for these widths use eight pixels per thread (W/8 threads, radix-8
+        // passes); every other V = 4 kernel sixteen pixels per thread (W/16 threads)
+        const bool eight = sizeof(T) == 4 && !p->injected && (W == 512 || W == 1024 || W == 2048 || W == 4096);
+        rc.threads = eight ? W / 8 : std::min(256, std::max(64, (W / 16 + 63) / 64 * 64));
     } else {
         if (W > 8192) return false;
         rc.V = 1;

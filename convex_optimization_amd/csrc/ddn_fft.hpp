@@ -354,40 +354,58 @@ __device__ __forceinline__ void fft_inverse(cx<T>* lds, int narr, int arr_stride
 // kernels' instruction footprint (which overflows the instruction cache).
 // ======================================================================================
 constexpr int ilog2_c(int n) { return n <= 1 ? 0 : 1 + ilog2_c(n >> 1); }
+// Two radix schedules: SCH = 16 (radix-16 first; identical to the host's factorize(), used wherever
+// the digit-reversed order is shared with stored multipliers, i.e. the column transforms) and
+// SCH = 8 (radix-8 first: one butterfly per thread per pass with N/8 threads; row transforms only,
+// whose digit-reversed order never leaves the workgroup).
+template <int SCH>
 constexpr int fixed_npass(int n) {
-    const int t = ilog2_c(n), a = t / 4, r = t % 4;
-    return t == 0 ? 0 : (r == 0 ? a : (r == 3 ? a + 1 : (a >= 1 ? a + 1 : 1)));
+    const int t = ilog2_c(n);
+    if (t == 0) return 0;
+    if (SCH == 16) {
+        const int a = t / 4, r = t % 4;
+        return r == 0 ? a : (r == 3 ? a + 1 : (a >= 1 ? a + 1 : 1));
+    }
+    const int a = t / 3, r = t % 3;
+    return r == 0 ? a : (r == 2 ? a + 1 : (a >= 1 ? a + 1 : 1));
 }
+template <int SCH>
 constexpr int fixed_radix(int n, int s) {
-    const int t = ilog2_c(n), a = t / 4, r = t % 4;
-    if (r == 0) return 16;
-    if (r == 3) return s < a ? 16 : 8;
-    if (r == 2) return a >= 1 ? (s < a - 1 ? 16 : 8) : 4;
-    return a >= 1 ? (s < a - 1 ? 16 : (s == a - 1 ? 8 : 4)) : 2;
+    const int t = ilog2_c(n);
+    if (SCH == 16) {
+        const int a = t / 4, r = t % 4;
+        if (r == 0) return 16;
+        if (r == 3) return s < a ? 16 : 8;
+        if (r == 2) return a >= 1 ? (s < a - 1 ? 16 : 8) : 4;
+        return a >= 1 ? (s < a - 1 ? 16 : (s == a - 1 ? 8 : 4)) : 2;
+    }
+    const int a = t / 3, r = t % 3;
+    if (r == 0) return 8;
+    if (r == 2) return s < a ? 8 : 4;          // 8 ... 8 4
+    return a >= 1 ? (s < a - 1 ? 8 : 4) : 2;   // 8 ... 8 4 4   (2^1: radix 2)
 }
+template <int SCH>
 constexpr int fixed_m(int n, int s) {  // n / (radix[0] * ... * radix[s])
     int m = n;
-    for (int i = 0; i <= s; ++i) m /= fixed_radix(n, i);
+    for (int i = 0; i <= s; ++i) m /= fixed_radix<SCH>(n, i);
     return m;
 }
 
-template <int N>
+template <int N, int SCH>
 __device__ __forceinline__ int pos_of_freq_fixed(int k) {
     int pos = 0;
 #pragma unroll
-    for (int s = 0; s < fixed_npass(N); ++s) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int r = fixed_radix(N, s);
-        pos += (k & (r - 1)) * fixed_m(N, s);
+    for (int s = 0; s < fixed_npass<SCH>(N); ++s) {
+        const int r = fixed_radix<SCH>(N, s);
+        pos += (k & (r - 1)) * fixed_m<SCH>(N, s);
         k /= r;
     }
     return pos;
 }
 
-template <typename T, int N, int S, bool INV>
+template <typename T, int N, int SCH, int S, bool INV>
 __device__ __forceinline__ void fixed_pass(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, int cshift, int tid, int nt) {
-    constexpr int R = fixed_radix(N, S), M = fixed_m(N, S), TWMUL = N / (M * R);
+    constexpr int R = fixed_radix<SCH>(N, S), M = fixed_m<SCH>(N, S), TWMUL = N / (M * R);
     const int per = (N / R) << cshift;
     const int total = per * narr;
     for (int w = tid; w < total; w += nt) {
@@ -403,36 +421,36 @@ __device__ __forceinline__ void fixed_pass(cx<T>* lds, int narr, int arr_stride,
     }
 }
 
-template <typename T, int N, int S = 0>
+template <typename T, int N, int SCH, int S = 0>
 __device__ __forceinline__ void fft_forward_fixed(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, int cshift, int tid, int nt) {
-    if constexpr (S < fixed_npass(N)) {
-        fixed_pass<T, N, S, false>(lds, narr, arr_stride, tw, cshift, tid, nt);
+    if constexpr (S < fixed_npass<SCH>(N)) {
+        fixed_pass<T, N, SCH, S, false>(lds, narr, arr_stride, tw, cshift, tid, nt);
         __syncthreads();
-        fft_forward_fixed<T, N, S + 1>(lds, narr, arr_stride, tw, cshift, tid, nt);
+        fft_forward_fixed<T, N, SCH, S + 1>(lds, narr, arr_stride, tw, cshift, tid, nt);
     }
 }
-template <typename T, int N, int S = fixed_npass(N) - 1>
+template <typename T, int N, int SCH, int S = fixed_npass<SCH>(N) - 1>
 __device__ __forceinline__ void fft_inverse_fixed(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, int cshift, int tid, int nt) {
     if constexpr (S >= 0) {
-        fixed_pass<T, N, S, true>(lds, narr, arr_stride, tw, cshift, tid, nt);
+        fixed_pass<T, N, SCH, S, true>(lds, narr, arr_stride, tw, cshift, tid, nt);
         __syncthreads();
-        fft_inverse_fixed<T, N, S - 1>(lds, narr, arr_stride, tw, cshift, tid, nt);
+        fft_inverse_fixed<T, N, SCH, S - 1>(lds, narr, arr_stride, tw, cshift, tid, nt);
     }
 }
 
-// Dispatchers: NF > 0 selects the specialised code, NF == 0 the generic run-time schedule.
-template <typename T, int NF>
+// Dispatchers: NF > 0 selects the specialised code (schedule SCH), NF == 0 the generic run-time schedule.
+template <typename T, int NF, int SCH = 16>
 __device__ __forceinline__ void fft_fwd(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int cshift, int tid, int nt) {
-    if constexpr (NF > 0) fft_forward_fixed<T, NF>(lds, narr, arr_stride, tw, cshift, tid, nt);
+    if constexpr (NF > 0) fft_forward_fixed<T, NF, SCH>(lds, narr, arr_stride, tw, cshift, tid, nt);
     else fft_forward<T>(lds, narr, arr_stride, tw, d, cshift, tid, nt);
 }
-template <typename T, int NF>
+template <typename T, int NF, int SCH = 16>
 __device__ __forceinline__ void fft_inv(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int cshift, int tid, int nt) {
-    if constexpr (NF > 0) fft_inverse_fixed<T, NF>(lds, narr, arr_stride, tw, cshift, tid, nt);
+    if constexpr (NF > 0) fft_inverse_fixed<T, NF, SCH>(lds, narr, arr_stride, tw, cshift, tid, nt);
     else fft_inverse<T>(lds, narr, arr_stride, tw, d, cshift, tid, nt);
 }
-template <int NF>
+template <int NF, int SCH = 16>
 __device__ __forceinline__ int pos_freq(const FftDesc& d, int k) {
-    if constexpr (NF > 0) return pos_of_freq_fixed<NF>(k);
+    if constexpr (NF > 0) return pos_of_freq_fixed<NF, SCH>(k);
     else return pos_of_freq(d, k);
 }

@@ -132,7 +132,7 @@ __device__ __forceinline__ void row_pack_load(cx<T> (&U)[KP], cx<T> (&V)[KP], in
         }
     }
 }
-template <typename T, int KP, int NF = 0>
+template <typename T, int KP, int NF = 0, int SCH = 16>
 __device__ __forceinline__ void row_pack_store(cx<T>* lds, const FftDesc& fw, int W, const cx<T> (&U)[KP], const cx<T> (&V)[KP], int tid, int nt) {
     const int half = W >> 1;
 #pragma unroll
@@ -141,48 +141,48 @@ __device__ __forceinline__ void row_pack_store(cx<T>* lds, const FftDesc& fw, in
         if (k <= half) {
             const int km = (k == 0) ? 0 : W - k;
             if (km == k) {
-                lds[SW(pos_freq<NF>(fw, k))] = mk<T>(U[i].x, V[i].x);  // DC / Nyquist of a real row: imaginary part dropped
+                lds[SW(pos_freq<NF, SCH>(fw, k))] = mk<T>(U[i].x, V[i].x);  // DC / Nyquist of a real row: imaginary part dropped
             } else {
-                lds[SW(pos_freq<NF>(fw, k))] = mk<T>(U[i].x - V[i].y, U[i].y + V[i].x);
-                lds[SW(pos_freq<NF>(fw, km))] = mk<T>(U[i].x + V[i].y, V[i].x - U[i].y);
+                lds[SW(pos_freq<NF, SCH>(fw, k))] = mk<T>(U[i].x - V[i].y, U[i].y + V[i].x);
+                lds[SW(pos_freq<NF, SCH>(fw, km))] = mk<T>(U[i].x + V[i].y, V[i].x - U[i].y);
             }
         }
     }
 }
 // KP * nt must cover W/2 + 1 entries (the callers' thread counts guarantee it).
-template <typename T, int KP, int NF = 0>
+template <typename T, int KP, int NF = 0, int SCH = 16>
 __device__ __forceinline__ void row_pack(cx<T>* lds, const FftDesc& fw, int W, const cx<T>* srcA, const SpecRow& ra, const cx<T>* srcB,
                                          const SpecRow& rb, int tid, int nt, const cx<T>* addA = nullptr, const cx<T>* addB = nullptr) {
     cx<T> U[KP], V[KP];
     row_pack_load<T, KP>(U, V, W, srcA, ra, srcB, rb, tid, nt, addA, addB);
-    row_pack_store<T, KP, NF>(lds, fw, W, U, V, tid, nt);
+    row_pack_store<T, KP, NF, SCH>(lds, fw, W, U, V, tid, nt);
 }
 // As row_pack but a single source multiplied by a row table (row-spectral D: U[k] * eD[k]).
-template <typename T, int NF = 0>
+template <typename T, int NF = 0, int SCH = 16>
 __device__ __forceinline__ void row_pack_mul(cx<T>* lds, const FftDesc& fw, int W, const cx<T>* srcA, const SpecRow& ra, const cx<T>* rowmul, int tid, int nt) {
     const int half = W >> 1;
     for (int k = tid; k <= half; k += nt) {
         cx<T> U = srcA[ra.at(k)] * rowmul[k];
         const int km = (k == 0) ? 0 : W - k;
         if (km == k) {
-            lds[SW(pos_freq<NF>(fw, k))] = mk<T>(U.x, 0);
+            lds[SW(pos_freq<NF, SCH>(fw, k))] = mk<T>(U.x, 0);
         } else {
-            lds[SW(pos_freq<NF>(fw, k))] = U;
-            lds[SW(pos_freq<NF>(fw, km))] = cconj(U);
+            lds[SW(pos_freq<NF, SCH>(fw, k))] = U;
+            lds[SW(pos_freq<NF, SCH>(fw, km))] = cconj(U);
         }
     }
 }
 // LDS holds the digit-reversed spectrum Z of a + i b.  Separate A = F(a), B = F(b) for k2 = 0..W/2
 // and store them (null destination = skip).  mulA != null: A is multiplied by conj(mulA[k]) first
 // (row-spectral D^T); accA adds to what dstA already holds.
-template <typename T, int NF = 0>
+template <typename T, int NF = 0, int SCH = 16>
 __device__ __forceinline__ void row_unpack(const cx<T>* lds, const FftDesc& fw, int W, cx<T>* dstA, const SpecRow& ra, cx<T>* dstB, const SpecRow& rb,
                                            const cx<T>* mulA, bool accA, int tid, int nt) {
     const int half = W >> 1;
     for (int k = tid; k <= half; k += nt) {
         const int km = (k == 0) ? 0 : W - k;
-        const cx<T> Z1 = lds[SW(pos_freq<NF>(fw, k))];
-        const cx<T> Z2 = lds[SW(pos_freq<NF>(fw, km))];
+        const cx<T> Z1 = lds[SW(pos_freq<NF, SCH>(fw, k))];
+        const cx<T> Z2 = lds[SW(pos_freq<NF, SCH>(fw, km))];
         if (dstA) {
             cx<T> A = mk<T>((T)0.5 * (Z1.x + Z2.x), (T)0.5 * (Z1.y - Z2.y));
             if (mulA) A = mulc(A, mulA[k]);
@@ -678,6 +678,7 @@ __global__ void __launch_bounds__(MAXT, MINW) k_solver_row(RowCommon<T> c, typen
     const int nrows = c.batch * c.H;
     constexpr int NH = SPEC ? NG : 1;
     constexpr int KP = (V * NG) / 2 + 1;  // half-spectrum entries per thread when nt = W / (V*NG)
+    constexpr int SCH = (V * NG == 8) ? 8 : 16;  // eight pixels per thread: radix-8 passes, one butterfly per thread
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int plane = row / c.H;
         if (c.stop && c.stop[plane] >= 0) continue;
@@ -705,9 +706,9 @@ __global__ void __launch_bounds__(MAXT, MINW) k_solver_row(RowCommon<T> c, typen
         DDN_STAMP(0)
         if (c.do_consume) {
             if (SPEC) {
-                row_pack_mul<T, WF>(L.data, c.fw, W, c.S0, sr, c.eDrow, tid, nt);
+                row_pack_mul<T, WF, SCH>(L.data, c.fw, W, c.S0, sr, c.eDrow, tid, nt);
                 __syncthreads();
-                fft_inv<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+                fft_inv<T, WF, SCH>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int j = (tid + g * nt) * V;
@@ -719,8 +720,8 @@ __global__ void __launch_bounds__(MAXT, MINW) k_solver_row(RowCommon<T> c, typen
                 __syncthreads();
             }
             if (!(c.dbg_mode & 2)) {
-                if (PF == 1) row_pack_store<T, KPF, WF>(L.data, c.fw, W, pU, pV, tid, nt);
-                else row_pack<T, KP, WF>(L.data, c.fw, W, c.S0, sr, c.S1, sr, tid, nt);
+                if (PF == 1) row_pack_store<T, KPF, WF, SCH>(L.data, c.fw, W, pU, pV, tid, nt);
+                else row_pack<T, KP, WF, SCH>(L.data, c.fw, W, c.S0, sr, c.S1, sr, tid, nt);
             } else if (PF == 1) {
                 T sacc = 0;
 #pragma unroll
@@ -729,7 +730,7 @@ __global__ void __launch_bounds__(MAXT, MINW) k_solver_row(RowCommon<T> c, typen
             }
             __syncthreads();
             DDN_STAMP(1)
-            if (!(c.dbg_mode & 1)) fft_inv<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+            if (!(c.dbg_mode & 1)) fft_inv<T, WF, SCH>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
             DDN_STAMP(2)
             if (!SPEC) {
 #pragma unroll
@@ -772,8 +773,12 @@ __global__ void __launch_bounds__(MAXT, MINW) k_solver_row(RowCommon<T> c, typen
                         prev = e.x;
                     }
                 }
-                if (PF) P::template step_regs<V>(a, c.do_consume != 0, c.do_produce != 0, ro + j, stq[g % NPF], u, k, du, re, im, s, acc);
-                else P::template step<V>(a, c.do_consume != 0, c.do_produce != 0, ro + j, u, k, du, re, im, s, acc);
+                const bool cons = c.do_consume != 0 && !(c.dbg_mode & 4);
+                if (c.dbg_mode & 8) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) { re[v] = u[v]; im[v] = k[v]; s[v] = du[v]; }
+                } else if (PF) P::template step_regs<V>(a, cons, c.do_produce != 0, ro + j, stq[g % NPF], u, k, du, re, im, s, acc);
+                else P::template step<V>(a, cons, c.do_produce != 0, ro + j, u, k, du, re, im, s, acc);
                 if (c.do_produce) {
                     if (SPEC) {
 #pragma unroll
@@ -816,9 +821,9 @@ __global__ void __launch_bounds__(MAXT, MINW) k_solver_row(RowCommon<T> c, typen
                 __syncthreads();
             }
             DDN_STAMP(6)
-            if (!(c.dbg_mode & 1)) fft_fwd<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+            if (!(c.dbg_mode & 1)) fft_fwd<T, WF, SCH>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
             DDN_STAMP(7)
-            if (!(c.dbg_mode & 2)) row_unpack<T, WF>(L.data, c.fw, W, c.S0, sr, c.S1, sr, nullptr, false, tid, nt);
+            if (!(c.dbg_mode & 2)) row_unpack<T, WF, SCH>(L.data, c.fw, W, c.S0, sr, c.S1, sr, nullptr, false, tid, nt);
             DDN_STAMP(8)
             if (SPEC) {
                 __syncthreads();
@@ -831,8 +836,8 @@ __global__ void __launch_bounds__(MAXT, MINW) k_solver_row(RowCommon<T> c, typen
                     }
                 }
                 __syncthreads();
-                fft_fwd<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
-                row_unpack<T, WF>(L.data, c.fw, W, c.S0, sr, nullptr, sr, c.eDrow, true, tid, nt);
+                fft_fwd<T, WF, SCH>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+                row_unpack<T, WF, SCH>(L.data, c.fw, W, c.S0, sr, nullptr, sr, c.eDrow, true, tid, nt);
             }
         }
     }
@@ -864,6 +869,7 @@ __global__ void __launch_bounds__(MAXT, MINW) k_cp_row(RowCommon<T> c, CpArgs<T>
     const int npairs = c.batch * ppp;
     constexpr int NH = SPEC ? NG : 1;
     constexpr int KP = (V * NG) / 2 + 1;
+    constexpr int SCH = (V * NG == 8) ? 8 : 16;
     for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const int plane = pr / ppp;
         const int r0 = (pr - plane * ppp) * 2;
@@ -886,13 +892,13 @@ __global__ void __launch_bounds__(MAXT, MINW) k_cp_row(RowCommon<T> c, CpArgs<T>
                     }
                 }
                 __syncthreads();
-                fft_fwd<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+                fft_fwd<T, WF, SCH>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
                 {
                     // both slots are multiplied by the Hermitian-extended eD: Z'[k] = eD[k] Z[k], Z'[W-k] = conj(eD[k]) Z[W-k]
                     const int half = W >> 1;
                     for (int k = tid; k <= half; k += nt) {
                         const int km = (k == 0) ? 0 : W - k;
-                        const int p1 = SW(pos_freq<WF>(c.fw, k)), p2 = SW(pos_freq<WF>(c.fw, km));
+                        const int p1 = SW(pos_freq<WF, SCH>(c.fw, k)), p2 = SW(pos_freq<WF, SCH>(c.fw, km));
                         const cx<T> e = c.eDrow[k];
                         const cx<T> Z1 = L.data[p1], Z2 = L.data[p2];
                         L.data[p1] = Z1 * e;
@@ -900,7 +906,7 @@ __global__ void __launch_bounds__(MAXT, MINW) k_cp_row(RowCommon<T> c, CpArgs<T>
                     }
                 }
                 __syncthreads();
-                fft_inv<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+                fft_inv<T, WF, SCH>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
                 const T sc = (T)1 / (T)W;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
@@ -917,9 +923,9 @@ __global__ void __launch_bounds__(MAXT, MINW) k_cp_row(RowCommon<T> c, CpArgs<T>
                 __syncthreads();
             }
             const bool addS1 = SPEC && a.step == 1;
-            row_pack<T, KP, WF>(L.data, c.fw, W, c.S0, sa, nslot == 2 ? c.S0 : (const cx<T>*)nullptr, sb, tid, nt, addS1 ? c.S1 : (const cx<T>*)nullptr, (addS1 && nslot == 2) ? c.S1 : (const cx<T>*)nullptr);
+            row_pack<T, KP, WF, SCH>(L.data, c.fw, W, c.S0, sa, nslot == 2 ? c.S0 : (const cx<T>*)nullptr, sb, tid, nt, addS1 ? c.S1 : (const cx<T>*)nullptr, (addS1 && nslot == 2) ? c.S1 : (const cx<T>*)nullptr);
             __syncthreads();
-            fft_inv<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+            fft_inv<T, WF, SCH>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
         }
         double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
@@ -1029,8 +1035,8 @@ __global__ void __launch_bounds__(MAXT, MINW) k_cp_row(RowCommon<T> c, CpArgs<T>
         }
         __syncthreads();
         if (c.do_produce) {
-            fft_fwd<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
-            row_unpack<T, WF>(L.data, c.fw, W, c.S0, sa, nslot == 2 ? c.S0 : nullptr, sb, nullptr, false, tid, nt);
+            fft_fwd<T, WF, SCH>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+            row_unpack<T, WF, SCH>(L.data, c.fw, W, c.S0, sa, nslot == 2 ? c.S0 : nullptr, sb, nullptr, false, tid, nt);
             if (SPEC && a.step == 0) {
                 __syncthreads();
 #pragma unroll
@@ -1049,13 +1055,13 @@ __global__ void __launch_bounds__(MAXT, MINW) k_cp_row(RowCommon<T> c, CpArgs<T>
                     }
                 }
                 __syncthreads();
-                fft_fwd<T, WF>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
+                fft_fwd<T, WF, SCH>(L.data, 1, 0, tw, c.fw, 0, tid, nt);
                 {
                     const int half = W >> 1;
                     const T hw = (T)0.5 / (T)W;  // 1/W: this spectrum skips the normalised column stage
                     for (int k = tid; k <= half; k += nt) {
                         const int km = (k == 0) ? 0 : W - k;
-                        const cx<T> Z1 = L.data[SW(pos_freq<WF>(c.fw, k))], Z2 = L.data[SW(pos_freq<WF>(c.fw, km))];
+                        const cx<T> Z1 = L.data[SW(pos_freq<WF, SCH>(c.fw, k))], Z2 = L.data[SW(pos_freq<WF, SCH>(c.fw, km))];
                         const cx<T> e = c.eDrow[k];
                         c.S1[sa.at(k)] = mulc(mk<T>(hw * (Z1.x + Z2.x), hw * (Z1.y - Z2.y)), e);
                         if (nslot == 2) c.S1[sb.at(k)] = mulc(mk<T>(hw * (Z1.y + Z2.y), hw * (Z2.x - Z1.x)), e);

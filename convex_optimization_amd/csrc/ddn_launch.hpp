@@ -55,7 +55,7 @@ int launch_row_fn(hipStream_t st, K fn, int grid, int threads, size_t lds, const
 // whole row's global loads in registers (PF).  V = 1: any W up to 8192, scalar accesses.
 template <typename T, class P, int WF>
 int row_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCommon<T>& c, const typename P::Args& a) {
-    return launch_row_fn(st, k_solver_row<T, P, 4, 4, false, 1, WF, 256, 2>, grid, threads, lds, c, a);
+    return launch_row_fn(st, k_solver_row<T, P, 4, 2, false, 1, WF, 512, 4>, grid, threads, lds, c, a);
 }
 
 template <typename T, class P>
@@ -80,7 +80,7 @@ int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const R
 
 template <typename T, int WF>
 int cp_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCommon<T>& c, const CpArgs<T>& a) {
-    return launch_row_fn(st, k_cp_row<T, 4, 4, false, WF, 256, 2>, grid, threads, lds, c, a);
+    return launch_row_fn(st, k_cp_row<T, 4, 2, false, WF, 512, 4>, grid, threads, lds, c, a);
 }
 
 template <typename T>

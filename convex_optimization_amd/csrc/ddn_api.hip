@@ -150,6 +150,7 @@ struct ddn_plan {
     int num_cu = 256;
     // device buffers (typed by dtype)
     void* twW = nullptr;
+    void* wtw = nullptr;     // per-lane twiddles of the wave-per-row kernels (W = 4096, float) or null
     void* twH = nullptr;   // table of length H (outer twiddles and single-pass column transform)
     void* twA = nullptr;
     void* twB = nullptr;
@@ -276,6 +277,18 @@ int plan_alloc(ddn_plan* p) {
     int rc;
     if ((rc = make_table<T>(p->W, (cx<T>**)&p->twW))) return rc;
     if ((rc = make_table<T>(p->H, (cx<T>**)&p->twH))) return rc;
+    if (sizeof(T) == 4 && p->W == 4096 && !getenv("DDN_NO_WAVE_ROWS")) {
+        // lane l: w^(l c), c = 0..7, then w^(8 l a), a = 0..7, w = exp(-2 pi i / 4096)
+        std::vector<cx<float>> tab(64 * 16);
+        const long double tp = -2.0L * 3.14159265358979323846264338327950288L / 4096.0L;
+        for (int l = 0; l < 64; ++l)
+            for (int i = 0; i < 8; ++i) {
+                tab[l * 16 + i] = {(float)cosl(tp * (l * i)), (float)sinl(tp * (l * i))};
+                tab[l * 16 + 8 + i] = {(float)cosl(tp * (8 * l * i)), (float)sinl(tp * (8 * l * i))};
+            }
+        HIPCHK(hipMalloc(&p->wtw, tab.size() * sizeof(cx<float>)));
+        HIPCHK(hipMemcpy(p->wtw, tab.data(), tab.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
+    }
     if ((rc = alloc_col_tables<T>(p))) return rc;
     if ((rc = alloc_spec<T>(p))) return rc;
     const int Wt = p->Wh + 64;
@@ -426,6 +439,12 @@ struct RowCfg {
 template <typename T>
 bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc) {
     const int W = p->W;
+    if (sizeof(T) == 4 && p->wtw && !p->injected) {
+        // one wavefront per row, eight per CU (256 registers each), the row held in registers
+        rc.V = 0; rc.threads = 64; rc.lds = 0;
+        rc.grid = std::max(1, std::min(work_items, p->num_cu * 8));
+        return true;
+    }
     if (aligned && W % 4 == 0 && W <= 4096) {
         rc.V = 4;
         // float kernels specialised for these widths use eight pixels per thread (W/8 threads, radix-8
@@ -451,7 +470,8 @@ RowCommon<T> row_common(ddn_plan* p, int V, bool consume, bool produce) {
     RowCommon<T> c;
     std::memset(&c, 0, sizeof(c));
     c.H = p->H; c.W = p->W; c.batch = p->batch;
-    c.V_groups = p->W / V;
+    c.V_groups = V ? p->W / V : 0;
+    c.wtw = (const cx<T>*)p->wtw;
     c.fw = p->fw;
     c.lay = layout_of(p);
     c.twW = (const cx<T>*)p->twW;
@@ -861,7 +881,7 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
 
 int ddn_plan_destroy(ddn_plan* p) {
     if (!p) return DDN_OK;
-    void* bufs[] = {p->twW, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
+    void* bufs[] = {p->twW, p->wtw, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : p->ev_pool) {

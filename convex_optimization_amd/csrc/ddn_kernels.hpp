@@ -28,15 +28,48 @@ __device__ __forceinline__ T soft(T v, T lam) {
     a = a > (T)0 ? a : (T)0;
     return v < (T)0 ? -a : a;
 }
+// v / d with d uniform: the fast units multiply by the hardware reciprocal (hoisted out of the pixel loops)
+template <typename T>
+__device__ __forceinline__ T udiv(T v, T d) {
+#ifdef DDN_WAVE_FAST
+    if constexpr (sizeof(T) == 4) return v * __builtin_amdgcn_rcpf(d);
+#endif
+    return v / d;
+}
+// data-term prox, l1 (objective 0) or squared l2: both sides are cheap, no branch
+template <typename T>
+__device__ __forceinline__ T data_prox(int objective, T v, T lam, T div);
 __device__ __forceinline__ float t_sqrt(float v) { return sqrtf(v); }
 __device__ __forceinline__ double t_sqrt(double v) { return sqrt(v); }
 // prox_iso (core/proximal_operators.py:22-50): per-pixel 2-vector shrink, zero where norm <= lam
+// Translation units that define DDN_WAVE_FAST (the wave-per-row float kernels) use the hardware
+// reciprocal square root (1 ulp) and no branch; every other unit the correctly rounded sqrt and divide.
 template <typename T>
 __device__ __forceinline__ void iso(T a, T c, T lam, T& oa, T& oc) {
+#ifdef DDN_WAVE_FAST
+    if constexpr (sizeof(T) == 4) {
+        const float n2 = a * a + c * c;
+        const float f = n2 > lam * lam ? 1.f - lam * __builtin_amdgcn_rsqf(n2) : 0.f;
+        oa = f * a;
+        oc = f * c;
+        return;
+    }
+#endif
     const T n = t_sqrt(a * a + c * c);
     const T f = n > lam ? (T)1 - lam / n : (T)0;
     oa = f * a;
     oc = f * c;
+}
+
+template <typename T>
+__device__ __forceinline__ T data_prox(int objective, T v, T lam, T div) {
+#ifdef DDN_WAVE_FAST
+    const T a = soft(v, lam), q = udiv(v, div);
+    return objective == 0 ? a : q;
+#else
+    if (objective == 0) return soft(v, lam);
+    return v / div;
+#endif
 }
 
 template <typename T, int V>
@@ -396,6 +429,7 @@ struct RowCommon {
     FftDesc fw;
     SpecLayout lay;
     const cx<T>* twW;    // global twiddle tables for W
+    const cx<T>* wtw;    // per-lane twiddles of the wave-per-row kernels ([64][16]) or null
     cx<T>* S0;
     cx<T>* S1;
     const cx<T>* eDrow;  // row-spectral D table (W/2+1 entries) or null = 2-tap stencils
@@ -443,7 +477,7 @@ struct PdrP {
     };
     static __device__ __forceinline__ void xy(const Args& a, T z1, T z20, T z21, T z22, T b, T& x, T& y0, T& y1, T& y2) {
         x = clip01(z1);                                                                           // pdr:96
-        if (a.objective == 0) y0 = b + soft(z20 - b, a.t); else y0 = b + (z20 - b) / a.l2div;      // pdr:105 / 110
+        y0 = b + data_prox(a.objective, z20 - b, a.t, a.l2div);                                   // pdr:105 / 110
         iso(z21, z22, a.tg, y1, y2);                                                              // pdr:103 / 108
     }
     template <int V>
@@ -628,7 +662,7 @@ struct AdmmP {
                 const T pp1 = a.rho * dx[v] + a.omr * y1[v] + a.it * z1[v];
                 const T pp2 = a.rho * dx[v] + a.omr * y2[v] + a.it * z2[v];
                 T y0n, y1n, y2n;
-                if (a.objective == 0) y0n = b[v] + soft(pp0 - b[v], a.it); else y0n = b[v] + (pp0 - b[v]) / a.l2div;  // admm:99-104
+                y0n = b[v] + data_prox(a.objective, pp0 - b[v], a.it, a.l2div);                   // admm:99-104
                 iso(pp1, pp2, a.itg, y1n, y2n);                                                   // admm:105
                 w[v] = w[v] + a.t * (x[v] - un);                                                  // admm:108
                 z0[v] = z0[v] + a.t * (kx[v] - y0n);                                              // admm:109

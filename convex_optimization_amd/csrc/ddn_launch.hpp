@@ -58,9 +58,17 @@ int row_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCom
     return launch_row_fn(st, k_solver_row<T, P, 4, 2, false, 1, WF, 512, 4>, grid, threads, lds, c, a);
 }
 
+// Wave-per-row kernels (W = 4096, float, 2-tap D; ddn_wrow.hpp), instantiated in ddn_wrow_*.hip.
+template <class P>
+int wrow_launch(hipStream_t st, int grid, const RowCommon<float>& c, const typename P::Args& a);
+int wrow_cp_launch(hipStream_t st, int grid, const RowCommon<float>& c, const CpArgs<float>& a);
+
 template <typename T, class P>
 int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const RowCommon<T>& c, const typename P::Args& a) {
     const bool spec = c.eDrow != nullptr;
+    if constexpr (sizeof(T) == 4) {
+        if (V == 0) return wrow_launch<P>(st, grid, c, a);
+    }
     if (V == 4) {
         if (spec) return launch_row_fn(st, k_solver_row<T, P, 4, 4, true, 0, 0, 256, 2>, grid, threads, lds, c, a);
         if constexpr (sizeof(T) == 4) {
@@ -86,6 +94,9 @@ int cp_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowComm
 template <typename T>
 int cp_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const RowCommon<T>& c, const CpArgs<T>& a) {
     const bool spec = c.eDrow != nullptr;
+    if constexpr (sizeof(T) == 4) {
+        if (V == 0) return wrow_cp_launch(st, grid, c, a);
+    }
     if (V == 4) {
         if (spec) return launch_row_fn(st, k_cp_row<T, 4, 4, true, 0, 256, 2>, grid, threads, lds, c, a);
         if constexpr (sizeof(T) == 4) {

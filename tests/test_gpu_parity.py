@@ -261,6 +261,45 @@ def test_config2_512_all_solvers_vs_oracle(pkg, golden_dir):
     assert rel(x.numpy(), xo.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("H", [24, 15])
+def test_width_4096_wave_rows_vs_oracle(pkg, golden_dir, H):
+    """W = 4096 float32 takes the one-wavefront-per-row kernels (the row held in registers): all four
+    solvers against the CPU oracle at H x 4096, N = 20; H = 15 covers the odd last row of
+    Chambolle-Pock's row pairs."""
+    k = _load(golden_dir, "kernels.npz")
+    kern = torch.from_numpy(k["motion15_45"])
+    W = 4096
+    torch.manual_seed(0)
+    img = torch.rand(1, H, W)
+    b = O.add_gaussian_noise(O.circular_convolve2d(img, kern), 0.0, 0.05)[0]
+    N = 20
+    torch.manual_seed(7)
+    st = (torch.rand(H, W), torch.rand(H, W), torch.rand(3, H, W))
+    xo = O.chambolle_pock(b[None], kern, max_iter=N + 1, init_state=st)
+    x = pkg.chambolle_pock_solver(b[None], kern, max_iter=N + 1, init_state=st)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    for obj in ("l1", "l2"):
+        stA = tuple(torch.clamp(torch.randn(s, dtype=torch.float32), 0, 1) for s in [(H, W), (H, W), (3, H, W), (3, H, W)])
+        lo, lg = [], []
+        xo = O.admm_solver(b, obj, kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, loss_function=O.psnr, losses=lo)
+        x, lg = pkg.admm_solver(b, obj, kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, return_losses=True)
+        assert rel(x.numpy(), xo.numpy()) < 1e-5
+        assert np.allclose(np.asarray(lg, dtype=np.float64), np.asarray(lo, dtype=np.float64), rtol=2e-5)
+        xo = O.primal_dr_splitting(obj, kern, b, niters=N)
+        x = pkg.primal_dr_splitting(obj, kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0)
+        assert rel(x.numpy(), xo.numpy()) < 1e-5
+    stP = (torch.rand(H, W), torch.rand(3, H, W))
+    xo = O.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP)
+    x = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP, tol=-1.0)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    # batch of two equals two single calls bit for bit
+    b2 = torch.stack((b, b.flip(0)))
+    xb = pkg.primal_dr_splitting("l1", kern, b2, niters=5, loss_function=pkg.core.mse, tol=-1.0)
+    for i in range(2):
+        xi = pkg.primal_dr_splitting("l1", kern, b2[i], niters=5, loss_function=pkg.core.mse, tol=-1.0)
+        assert np.array_equal(xb[i].numpy(), xi.numpy())
+
+
 def test_batch_equals_loop_of_single_calls(pkg, golden_dir):
     k = _load(golden_dir, "kernels.npz")
     kern = k["gauss9"]

@@ -150,7 +150,10 @@ struct ddn_plan {
     int num_cu = 256;
     // device buffers (typed by dtype)
     void* twW = nullptr;
-    void* wtw = nullptr;     // per-lane twiddles of the wave-per-row kernels (W = 4096, float) or null
+    void* wtw = nullptr;     // per-lane twiddles of the register-resident 4096-point transform (float) or null
+    void* eKc = nullptr;     // column-major natural-order copies of eK and G for the wave-per-column stage
+    void* Gcm = nullptr;
+    bool eKc_ok = false, Gcm_ok = false;
     void* twH = nullptr;   // table of length H (outer twiddles and single-pass column transform)
     void* twA = nullptr;
     void* twB = nullptr;
@@ -277,7 +280,7 @@ int plan_alloc(ddn_plan* p) {
     int rc;
     if ((rc = make_table<T>(p->W, (cx<T>**)&p->twW))) return rc;
     if ((rc = make_table<T>(p->H, (cx<T>**)&p->twH))) return rc;
-    if (sizeof(T) == 4 && p->W == 4096 && !getenv("DDN_NO_WAVE_ROWS")) {
+    if (sizeof(T) == 4 && (p->W == 4096 || p->H == 4096)) {
         // lane l: w^(l c), c = 0..7, then w^(8 l a), a = 0..7, w = exp(-2 pi i / 4096)
         std::vector<cx<float>> tab(64 * 16);
         const long double tp = -2.0L * 3.14159265358979323846264338327950288L / 4096.0L;
@@ -367,11 +370,40 @@ inline int col_threads_for(const ddn_plan* p, int n, int cs, int narr) {
     return threads;
 }
 
+inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
+
+inline bool wcol_ready(const ddn_plan* p) {
+    return p->eKc_ok && p->wtw && p->H == 4096 && p->cs == 4 && !p->injected && !getenv("DDN_NO_WAVE_COLS");
+}
+// column-major natural-order copy of a tiled multiplier (complex and / or real)
+template <typename T>
+int make_colmajor(ddn_plan* p, const cx<T>* tiled, const T* tiled_real, void** outc, void** outr) {
+    const size_t total = (size_t)p->H * p->Wh;
+    if (outc && !*outc) HIPCHK(hipMalloc(outc, total * sizeof(cx<T>)));
+    if (outr && !*outr) HIPCHK(hipMalloc(outr, total * sizeof(T)));
+    hipLaunchKernelGGL(wcol::k_mult_colmajor<T>, dim3(ew_grid(total)), dim3(256), 0, p->stream, tiled, tiled_real,
+                       outc ? (cx<T>*)*outc : nullptr, outr ? (T*)*outr : nullptr, p->H, p->Wh, layout_of(p), colmap<T>(p));
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
 // One full column stage (forward, pointwise algebra, inverse) in place on S0 (and S1).
 // MODE as in ddn_kernels.hpp; nplanes = images to process.
 template <typename T, int MODE>
 int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const cx<T>* gcplx, int conj_mult, T scale, const LossFin& lf) {
     constexpr int NARR = (MODE == COL_RES2) ? 2 : 1;
+    if constexpr (sizeof(T) == 4 && (MODE == COL_RES2 || MODE == COL_MUL)) {
+        // H = 4096: one pass, one wavefront per column (ddn_wcol.hpp)
+        if (wcol_ready(p) && mult == (const cx<T>*)p->eK && !gcplx && (MODE == COL_MUL || (greal == (const T*)p->G && p->Gcm_ok))) {
+            wcol::Args w;
+            std::memset(&w, 0, sizeof(w));
+            w.S0 = (cx<float>*)p->S0; w.S1 = (cx<float>*)p->S1;
+            w.eKc = (const cx<float>*)p->eKc; w.Gc = (const float*)p->Gcm; w.wtw = (const cx<float>*)p->wtw;
+            w.lay = layout_of(p); w.Wh = p->Wh; w.batch = nplanes; w.conj_mult = conj_mult; w.scale = (float)scale; w.lf = lf;
+            TimerScope ts(p, false);
+            return wcol_launch(p->stream, MODE, w);
+        }
+    }
     ColArgs<T> a;
     std::memset(&a, 0, sizeof(a));
     a.S0 = (cx<T>*)p->S0;
@@ -439,7 +471,7 @@ struct RowCfg {
 template <typename T>
 bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc) {
     const int W = p->W;
-    if (sizeof(T) == 4 && p->wtw && !p->injected) {
+    if (sizeof(T) == 4 && p->wtw && W == 4096 && !p->injected && !getenv("DDN_NO_WAVE_ROWS")) {
         // one wavefront per row, eight per CU (256 registers each), the row held in registers
         rc.V = 0; rc.threads = 64; rc.lds = 0;
         rc.grid = std::max(1, std::min(work_items, p->num_cu * 8));
@@ -576,7 +608,6 @@ int rows_c2r(ddn_plan* p, T* dst, int nplanes, T scale, const T* add) {
     return DDN_OK;
 }
 
-inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
 
 // y = real(ifft2(m * fft2(x))) with a position-ordered half-plane multiplier
 template <typename T>
@@ -645,6 +676,7 @@ int set_resolvent_impl(ddn_plan* p, double cK, double cD, const void* M_dev, int
         int rc = import_full<T>(p, M_dev, cdtype, 1, 0, scale, (cx<T>*)p->Gc, (T*)p->G);
         if (rc) return rc;
         p->have_G = true;
+        p->Gcm_ok = false;
         return DDN_OK;
     }
     if (!p->have_K) return fail(DDN_E_STATE, "set_resolvent: no blur kernel set");
@@ -653,6 +685,12 @@ int set_resolvent_impl(ddn_plan* p, double cK, double cD, const void* M_dev, int
                        p->H, p->Wh, layout_of(p), (T)cK, (T)cD, (T)scale);
     HIPCHK(hipGetLastError());
     p->have_G = true;
+    p->Gcm_ok = false;
+    if (sizeof(T) == 4 && p->eKc_ok) {
+        int rc = make_colmajor<T>(p, nullptr, (const T*)p->G, nullptr, &p->Gcm);
+        if (rc) return rc;
+        p->Gcm_ok = true;
+    }
     return DDN_OK;
 }
 
@@ -881,7 +919,7 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
 
 int ddn_plan_destroy(ddn_plan* p) {
     if (!p) return DDN_OK;
-    void* bufs[] = {p->twW, p->wtw, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
+    void* bufs[] = {p->twW, p->wtw, p->eKc, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : p->ev_pool) {
@@ -924,6 +962,11 @@ int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
     if (rc) return rc;
     p->have_K = true;
     p->injected = false;
+    p->eKc_ok = p->Gcm_ok = false;
+    if (p->dtype == DDN_F32 && p->wtw && p->H == 4096 && p->cs == 4) {
+        if ((rc = make_colmajor<float>(p, (const cx<float>*)p->eK, nullptr, &p->eKc, nullptr))) return rc;
+        p->eKc_ok = true;
+    }
     return DDN_OK;
 }
 
@@ -934,6 +977,7 @@ int ddn_plan_set_eig(ddn_plan* p, const void* eigK, const void* eigD, int cdtype
     else rc = import_full<double>(p, eigK, cdtype, 0, 0, 1.0, (cx<double>*)p->eK, nullptr);
     if (rc) return rc;
     p->have_K = true;
+    p->eKc_ok = p->Gcm_ok = false;
     // row-spectral D table: Hermitian-symmetrised first row of eigD, or the analytic 1 - w^k
     const int W = p->W, Wh = p->Wh;
     std::vector<double> row(2 * (size_t)W);

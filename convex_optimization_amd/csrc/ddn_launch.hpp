@@ -11,6 +11,7 @@
 
 #include "../../include/ddn.h"
 #include "ddn_kernels.hpp"
+#include "ddn_wcol_args.hpp"
 
 inline std::string& ddn_err() {
     thread_local std::string e;
@@ -62,6 +63,8 @@ int row_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCom
 template <class P>
 int wrow_launch(hipStream_t st, int grid, const RowCommon<float>& c, const typename P::Args& a);
 int wrow_cp_launch(hipStream_t st, int grid, const RowCommon<float>& c, const CpArgs<float>& a);
+// Wave-per-column single-pass column stage (H = 4096, float; ddn_wcol.hpp), in ddn_wcol.hip.
+int wcol_launch(hipStream_t st, int mode, const wcol::Args& a);
 
 template <typename T, class P>
 int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const RowCommon<T>& c, const typename P::Args& a) {

@@ -142,6 +142,7 @@ struct ddn_plan {
     FftDesc fw{}, fh{}, fa{}, fb{};
     int A = 1, B = 1;          // column transform split H = A x B (A = 1: one pass)
     int cs = 0, ntile = 1;     // spectral arrays are stored in tiles of C = 1 << cs columns
+    int tile_pad_rows = 0;
     size_t spec_plane = 0;     // complex elements of one image's half-spectrum (ntile * H * C)
     int col_threads = 0;
     int row_threads = 0;       // 0 = heuristic
@@ -154,6 +155,7 @@ struct ddn_plan {
     void* eKc = nullptr;     // column-major natural-order copies of eK and G for the wave-per-column stage
     void* Gcm = nullptr;
     bool eKc_ok = false, Gcm_ok = false;
+    double g_cK = 0, g_cD = 0;  // coefficients of the closed-form resolvent multiplier (when Gcm_ok)
     void* twH = nullptr;   // table of length H (outer twiddles and single-pass column transform)
     void* twA = nullptr;
     void* twB = nullptr;
@@ -185,7 +187,7 @@ size_t col_lds_bytes(int n, int cshift, int narr) {
 
 SpecLayout layout_of(const ddn_plan* p) {
     SpecLayout l;
-    l.H = p->H;
+    l.H = p->H + p->tile_pad_rows;  // row pitch of a tile (rows beyond H are padding)
     l.cs = p->cs;
     l.ntile = p->ntile;
     return l;
@@ -234,7 +236,11 @@ bool choose_col(ddn_plan* p) {
     }
     p->cs = std::min(c2, lim);
     p->ntile = (p->Wh + (1 << p->cs) - 1) >> p->cs;
-    p->spec_plane = ((size_t)p->ntile * p->H) << p->cs;
+    // tiles a power of two apart would put the rows that resident workgroups stream in lockstep at the
+    // same offset modulo the DRAM channel interleave: pad the tile pitch for large power-of-two heights
+    p->tile_pad_rows = 0;
+    if (p->H >= 1024 && (p->H & (p->H - 1)) == 0) p->tile_pad_rows = getenv("DDN_TILE_PAD_ROWS") ? atoi(getenv("DDN_TILE_PAD_ROWS")) : 0;
+    p->spec_plane = ((size_t)p->ntile * (p->H + p->tile_pad_rows)) << p->cs;
     return true;
 }
 
@@ -303,8 +309,8 @@ int plan_alloc(ddn_plan* p) {
     HIPCHK(hipMalloc((void**)&p->partials, (size_t)p->batch * p->H * 4 * sizeof(double)));
     HIPCHK(hipMemset(p->partials, 0, (size_t)p->batch * p->H * 4 * sizeof(double)));
     if (getenv("DDN_DEBUG_STAMPS")) {
-        HIPCHK(hipMalloc((void**)&p->dbg, 4096 * 16 * sizeof(long long)));
-        HIPCHK(hipMemset(p->dbg, 0, 4096 * 16 * sizeof(long long)));
+        HIPCHK(hipMalloc((void**)&p->dbg, 2 * 4096 * 16 * sizeof(long long)));
+        HIPCHK(hipMemset(p->dbg, 0, 2 * 4096 * 16 * sizeof(long long)));
     }
     HIPCHK(hipMalloc((void**)&p->stop, (size_t)p->batch * sizeof(int)));
     HIPCHK(hipMemset(p->stop, 0xff, (size_t)p->batch * sizeof(int)));
@@ -379,8 +385,9 @@ inline bool wcol_ready(const ddn_plan* p) {
 template <typename T>
 int make_colmajor(ddn_plan* p, const cx<T>* tiled, const T* tiled_real, void** outc, void** outr) {
     const size_t total = (size_t)p->H * p->Wh;
-    if (outc && !*outc) HIPCHK(hipMalloc(outc, total * sizeof(cx<T>)));
-    if (outr && !*outr) HIPCHK(hipMalloc(outr, total * sizeof(T)));
+    const size_t padded = (size_t)wcol::kColPitch * p->Wh;
+    if (outc && !*outc) HIPCHK(hipMalloc(outc, padded * sizeof(cx<T>)));
+    if (outr && !*outr) HIPCHK(hipMalloc(outr, padded * sizeof(T)));
     hipLaunchKernelGGL(wcol::k_mult_colmajor<T>, dim3(ew_grid(total)), dim3(256), 0, p->stream, tiled, tiled_real,
                        outc ? (cx<T>*)*outc : nullptr, outr ? (T*)*outr : nullptr, p->H, p->Wh, layout_of(p), colmap<T>(p));
     HIPCHK(hipGetLastError());
@@ -398,8 +405,11 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
             wcol::Args w;
             std::memset(&w, 0, sizeof(w));
             w.S0 = (cx<float>*)p->S0; w.S1 = (cx<float>*)p->S1;
-            w.eKc = (const cx<float>*)p->eKc; w.Gc = (const float*)p->Gcm; w.wtw = (const cx<float>*)p->wtw;
+            w.eKc = (const cx<float>*)p->eKc; w.wtw = (const cx<float>*)p->wtw;
+            w.ed2 = (const float*)p->ed2; w.cK = (float)p->g_cK; w.cD = (float)p->g_cD; w.gscale = (float)(1.0 / ((double)p->H * (double)p->W));
             w.lay = layout_of(p); w.Wh = p->Wh; w.batch = nplanes; w.conj_mult = conj_mult; w.scale = (float)scale; w.lf = lf;
+            w.dbg = p->dbg ? p->dbg + 4096 * 16 : nullptr;  // second half of the stamp buffer
+            w.dbg_mode = getenv("DDN_DEBUG_CMODE") ? atoi(getenv("DDN_DEBUG_CMODE")) : 0;
             TimerScope ts(p, false);
             return wcol_launch(p->stream, MODE, w);
         }
@@ -686,11 +696,8 @@ int set_resolvent_impl(ddn_plan* p, double cK, double cD, const void* M_dev, int
     HIPCHK(hipGetLastError());
     p->have_G = true;
     p->Gcm_ok = false;
-    if (sizeof(T) == 4 && p->eKc_ok) {
-        int rc = make_colmajor<T>(p, nullptr, (const T*)p->G, nullptr, &p->Gcm);
-        if (rc) return rc;
-        p->Gcm_ok = true;
-    }
+    p->g_cK = cK; p->g_cD = cD;
+    p->Gcm_ok = true;  // G is the closed form of eK: the wave-per-column stage recomputes it
     return DDN_OK;
 }
 
@@ -1137,7 +1144,7 @@ int ddn_pddr_run(ddn_plan* p, void* pp, void* q, const void* b, double t, double
 int ddn_plan_debug_stamps(ddn_plan* p, long long* out_host, int n_wg) {
     if (!p || !p->dbg) return fail(DDN_E_STATE, "debug stamps are off (set DDN_DEBUG_STAMPS=1 before plan_create)");
     HIPCHK(hipStreamSynchronize(p->stream));
-    HIPCHK(hipMemcpy(out_host, p->dbg, sizeof(long long) * 16 * (size_t)std::min(n_wg, 4096), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_host, p->dbg, sizeof(long long) * 16 * (size_t)std::min(n_wg, 8192), hipMemcpyDeviceToHost));
     return DDN_OK;
 }
 

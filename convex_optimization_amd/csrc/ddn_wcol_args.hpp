@@ -6,17 +6,24 @@
 
 namespace wcol {
 
+// Column pitch of the column-major multiplier copies: 4096 + 64 elements, so that the columns the
+// resident waves stream in lockstep do not all sit at the same offset modulo the DRAM channel interleave.
+constexpr int kColPitch = 4096 + 64;
+
 struct Args {
     cx<float>* S0;
     cx<float>* S1;
-    const cx<float>* eKc;  // [Wh][4096], natural frequency order along the column
-    const float* Gc;       // [Wh][4096]
+    const cx<float>* eKc;  // [Wh][kColPitch], natural frequency order along the column
+    const float* ed2;      // |eD|^2 per column (Wh entries): the resolvent multiplier is recomputed per frequency,
+    float cK, cD, gscale;  //   g = gscale / (1 + cK |e|^2 + cD ed2[k2])  (mm:67-72), which saves reading a third array
     const cx<float>* wtw;  // per-lane twiddles of the 4096-point transform
     SpecLayout lay;
     int Wh, batch;
     int conj_mult;
     float scale;
     LossFin lf;
+    long long* dbg;        // diagnostic: per-workgroup phase stamps (16 per workgroup) or null
+    int dbg_mode;          // diagnostic ablations (results wrong by construction): bit0 no multiplier loads, bit1 no exchange, bit2 every slab reads slab 0
 };
 
 // Column-major natural-order copies of the multipliers: outc[k2][k1] = tiled[pos(k1)][k2].
@@ -26,8 +33,9 @@ __global__ void k_mult_colmajor(const cx<T>* tiled, const T* tiled_real, cx<T>* 
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k2 = (int)(i / H), k1 = (int)(i - (size_t)k2 * H);
         const size_t o = spec_row(lay, 0, colpos_of_freq(cm, k1)).at(k2);
-        if (outc) outc[i] = tiled[o];
-        if (outr) outr[i] = tiled_real[o];
+        const size_t j = (size_t)k2 * kColPitch + k1;
+        if (outc) outc[j] = tiled[o];
+        if (outr) outr[j] = tiled_real[o];
     }
 }
 

@@ -176,7 +176,8 @@ int ddn_plan_enable_timing(ddn_plan* p, int on);
 
 /* Diagnostic (no counterpart in the reference): when the environment variable DDN_DEBUG_STAMPS=1 was
  * set at plan creation, copies the clock stamps the fused row kernel took at its phase boundaries in
- * its last launch (16 int64 per workgroup, first n_wg workgroups) to host memory. */
+ * its last launch (16 int64 per workgroup, first n_wg workgroups) to host memory; workgroups 4096.. of
+ * the buffer (n_wg up to 8192) are the stamps of the last single-pass column kernel. */
 int ddn_plan_debug_stamps(ddn_plan* p, long long* out_host, int n_wg);
 
 #ifdef __cplusplus

@@ -1,0 +1,33 @@
+import os, sys, ctypes as C
+os.environ["DDN_DEBUG_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np, torch
+import convex_optimization_amd as pkg
+from convex_optimization_amd import _lib as L
+from convex_optimization_amd.plan import _ptr
+from convex_optimization_amd.core.blur import create_motion_blur_kernel
+H = W = 4096
+dev = torch.device("cuda", 0)
+kern = create_motion_blur_kernel(15, 45)
+b = torch.rand(1, H, W, device=dev)
+ops = pkg.DeblurDenoiseOperators(kern, b[0], 2.0, device=dev, batch=1)
+st = [b.clone(), torch.stack((b, b, b)).contiguous()]
+lib = L.lib()
+lib.ddn_plan_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+L.check(lib.ddn_pdr_run(ops.plan._h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 2.0, 0.1, 0.049, 0, 4, 0, -1.0, 3, C.c_void_p(0), C.c_void_p(0)))
+torch.cuda.synchronize()
+buf = np.zeros((8192, 16), dtype=np.int64)
+L.check(lib.ddn_plan_debug_stamps(ops.plan._h, buf.ctypes.data_as(C.c_void_p), 8192))
+c = buf[4096:4096 + 544, :6]
+ok = c[:, 5] > 0
+print("column workgroups with stamps:", ok.sum())
+t0 = c[ok, 0].min()
+d = np.diff(c[ok], axis=1).astype(np.float64)
+for i, nm in enumerate(["load", "fft", "pointwise", "ifft", "store"]):
+    print(f"{nm:10s} median {np.median(d[:, i]):9.0f}  mean {d[:, i].mean():9.0f}  max {d[:, i].max():9.0f}")
+st_ = c[ok, 0] - t0; en = c[ok, 5] - t0
+print("start: min/median/max", st_.min(), np.median(st_), st_.max())
+print("end:   min/median/max", en.min(), np.median(en), en.max())
+print("per-WG total median", np.median(en - st_))
+order = np.argsort(st_)
+print("starts (sorted, every 32nd):", st_[order][::32])

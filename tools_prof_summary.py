@@ -4,13 +4,18 @@ import csv, glob, sys, collections, os
 root = sys.argv[1]
 def short(n):
     n = n.split('(')[0]
-    for k in ['k_solver_row', 'k_cp_row', 'k_col', 'k_rows_r2c', 'k_rows_c2r', 'k_loss_finalize', 'k_iters_done']:
+    for k in ['k_wave_row', 'k_wave_cp', 'k_wave_col', 'k_solver_row', 'k_cp_row', 'k_col', 'k_rows_r2c', 'k_rows_c2r', 'k_loss_finalize', 'k_iters_done']:
         if k in n:
             tag = k
             if 'PdrP' in n: tag += '<pdr>'
             elif 'PddrP' in n: tag += '<pddr>'
             elif 'AdmmP' in n: tag += '<admm>'
-            if 'k_col' in k:
+            if k == 'k_wave_col': tag += '<res2>' if 'Li0E' in n or '<0>' in n else '<mul>'
+            if k in ('k_wave_row', 'k_wave_cp'):
+                import re
+                m = re.search(r'(Lb[01]ELb[01]E|Li[01]ELb[01]ELb[01]E)', n)
+                if m: tag += '<' + m.group(1).replace('Lb','').replace('Li','').replace('E','') + '>'
+            if k == 'k_col':
                 import re
                 m = re.search(r'k_colI[fd]Li(\d)', n) or re.search(r'k_col<\w+, (\d)', n)
                 if m: tag += f'<mode{m.group(1)}>'

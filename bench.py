@@ -34,6 +34,11 @@ WORDS_ITER = {"chambolle_pock": 23, "primal_dr_splitting": 18, "primal_dual_dr_s
 # half-spectra in + 2 out; Chambolle-Pock launches two row kernels per iteration (dual 10 + primal 7).
 WORDS_ROW = {"chambolle_pock": 17 / 2.0, "primal_dr_splitting": 13, "primal_dual_dr_splitting": 13, "admm_solver": 21}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+# HBM bytes per launch of each fused row kernel at 4096 x 4096, one image, from the rocprofv3 PMC passes
+# whose summary is committed as profiles/r01_b_rocprofv3_summary.txt (separate --pmc runs of this
+# same command): 2 x FETCH_SIZE (gfx950 reports half of the bytes of streaming reads) + WRITE_SIZE, KB -> bytes.
+MEASURED_TRAFFIC_4096 = {"k_admm_row": 2 * 387.6e6 + 713.4e6, "k_pdr_row": 2 * 226.2e6 + 363.0e6,
+                         "k_pddr_row": 2 * 226.5e6 + 363.8e6, "k_cp_row": 2 * 185.8e6 + 241.8e6}
 
 
 def main():
@@ -49,6 +54,7 @@ def main():
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--row-threads", type=int, default=0)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events (roofline fields become null)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,7 +139,9 @@ def main():
         if Wm > 0:
             run(Wm, ring)
         barrier()
-        ops.plan.enable_timing(True)
+        # kernel durations are sampled: every 3rd row launch and every 3rd column launch carries HIP events
+        # (an odd stride, so that both alternating Chambolle-Pock kernels are sampled)
+        ops.plan.enable_timing(0 if args.no_kernel_timing else 3)
         t0 = time.perf_counter()
         run(K, ring)
         if distributed:
@@ -163,6 +171,7 @@ def main():
         del st, ring
         torch.cuda.empty_cache()
 
+    DOMK = {"chambolle_pock": "k_cp_row", "primal_dr_splitting": "k_pdr_row", "primal_dual_dr_splitting": "k_pddr_row", "admm_solver": "k_admm_row"}
     nsol = len(solvers)
     px = float(B) * H * W
     value = world * px * K * nsol / total_time / 1e6
@@ -177,8 +186,9 @@ def main():
         "config": {"workload": f"{H}x{W} grayscale motion-blur (15 taps @45deg) deconvolution, fp32, all four solvers, reference default parameters",
                    "images_per_gpu": B, "solvers": solvers, "step": "one iteration of each solver"},
         "per_solver": per_solver,
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": {"chambolle_pock": "k_cp_row", "primal_dr_splitting": "k_pdr_row", "primal_dual_dr_splitting": "k_pddr_row", "admm_solver": "k_admm_row"}[dom],
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": MEASURED_TRAFFIC_4096.get(DOMK[dom]) if (H == 4096 and W == 4096 and B == 1) else None,
+                     "kernel": DOMK[dom],
                      "algorithmic_bytes_per_launch": WORDS_ROW[dom] * 4.0 * px,
                      "whole_iteration_frac": {s: per_solver[s]["iter_hbm_frac"] for s in per_solver}},
     }

@@ -173,6 +173,8 @@ struct ddn_plan {
     long long* dbg = nullptr;    // diagnostic phase stamps (DDN_DEBUG_STAMPS=1), 16 per workgroup
     // timing
     bool timing = false;
+    int timing_stride = 1;       // every n-th row launch and every n-th column launch is bracketed by events
+    unsigned timing_count[2] = {0, 0};
     std::vector<EvPair> ev_row, ev_col;
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
@@ -324,6 +326,7 @@ struct TimerScope {
     EvPair ev{};
     bool on;
     TimerScope(ddn_plan* p_, bool row) : p(p_), vec(row ? &p_->ev_row : &p_->ev_col), on(p_->timing) {
+        if (on) on = (p->timing_count[row ? 0 : 1]++ % (unsigned)p->timing_stride) == 0;
         if (!on) return;
         if (p->ev_used == p->ev_pool.size()) {
             EvPair e;
@@ -407,7 +410,10 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
             w.S0 = (cx<float>*)p->S0; w.S1 = (cx<float>*)p->S1;
             w.eKc = (const cx<float>*)p->eKc; w.wtw = (const cx<float>*)p->wtw;
             w.ed2 = (const float*)p->ed2; w.cK = (float)p->g_cK; w.cD = (float)p->g_cD; w.gscale = (float)(1.0 / ((double)p->H * (double)p->W));
-            w.lay = layout_of(p); w.Wh = p->Wh; w.batch = nplanes; w.conj_mult = conj_mult; w.scale = (float)scale; w.lf = lf;
+            w.lay = layout_of(p); w.Wh = p->Wh; w.batch = nplanes;
+            // experimental: columns 0 and W/2 share one wave (exact, but its workgroup is slower than a plain one)
+            w.nyq_packed = (p->W % 2 == 0 && getenv("DDN_NYQ_PACK")) ? 1 : 0;
+            w.conj_mult = conj_mult; w.scale = (float)scale; w.lf = lf;
             w.dbg = p->dbg ? p->dbg + 4096 * 16 : nullptr;  // second half of the stamp buffer
             w.dbg_mode = getenv("DDN_DEBUG_CMODE") ? atoi(getenv("DDN_DEBUG_CMODE")) : 0;
             TimerScope ts(p, false);
@@ -1151,6 +1157,8 @@ int ddn_plan_debug_stamps(ddn_plan* p, long long* out_host, int n_wg) {
 int ddn_plan_enable_timing(ddn_plan* p, int on) {
     if (!p) return fail(DDN_E_ARG, "null plan");
     p->timing = on != 0;
+    p->timing_stride = on > 1 ? on : 1;
+    p->timing_count[0] = p->timing_count[1] = 0;
     return DDN_OK;
 }
 

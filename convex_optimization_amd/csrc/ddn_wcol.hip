@@ -3,16 +3,19 @@
 #include "ddn_launch.hpp"
 #include "ddn_wcol.hpp"
 
-int wcol_launch(hipStream_t st, int mode, const wcol::Args& a) {
-    const int grid = a.batch * 32 * ((a.lay.ntile + 7) / 8);
-    int rc;
-    if (mode == COL_RES2) {
-        if ((rc = ensure_lds_attr((const void*)wcol::k_wave_col<COL_RES2>))) return rc;
-        hipLaunchKernelGGL((wcol::k_wave_col<COL_RES2>), dim3(grid), dim3(512), 8 * wcol::kLdsBytes, st, a);
-    } else {
-        if ((rc = ensure_lds_attr((const void*)wcol::k_wave_col<COL_MUL>))) return rc;
-        hipLaunchKernelGGL((wcol::k_wave_col<COL_MUL>), dim3(grid), dim3(256), 4 * wcol::kLdsBytes, st, a);
-    }
+template <int MODE, bool PACKED>
+static int wcol_go(hipStream_t st, int grid, const wcol::Args& a) {
+    constexpr int waves = MODE == COL_RES2 ? 8 : 4;
+    auto fn = wcol::k_wave_col<MODE, PACKED>;
+    int rc = ensure_lds_attr((const void*)fn);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), waves * wcol::kLdsBytes + wcol::kLdsExtra, st, a);
     HIPCHK(hipGetLastError());
     return DDN_OK;
+}
+
+int wcol_launch(hipStream_t st, int mode, const wcol::Args& a) {
+    const int grid = a.batch * 32 * ((a.lay.ntile + 7) / 8);
+    if (mode == COL_RES2) return a.nyq_packed ? wcol_go<COL_RES2, true>(st, grid, a) : wcol_go<COL_RES2, false>(st, grid, a);
+    return a.nyq_packed ? wcol_go<COL_MUL, true>(st, grid, a) : wcol_go<COL_MUL, false>(st, grid, a);
 }

@@ -26,6 +26,7 @@ using wrow::sched_fence;
 constexpr int kSlabs = 16;                 // row slabs (of 64 rows) staged per round
 constexpr int kSlabPitch = 4 * 64 + 16;    // complex elements per staged slab (row pitch padded every 4 rows)
 constexpr size_t kLdsBytes = WFFT_TILE_FLOATS * sizeof(float);  // per wave
+constexpr size_t kLdsExtra = 2 * 64 * sizeof(cx<float>);          // lane-0 tables of the packed pair
 
 // Row-major global <-> column-owner registers for one quarter tile (4 columns), executed by the
 // four waves wq = 0..3 of a half; wave wq ends up with column wq: lane l, register r = row 64 r + l.
@@ -37,7 +38,7 @@ __device__ __forceinline__ void load_quarter(cx<float> (&d)[64], const cx<float>
     const int rd = 4 * lane + wq + (lane >> 2);
     // every global load of the column is issued before the first use: 64 x 512 bytes in flight per wave
 #pragma unroll
-    for (int r = 0; r < 64; ++r) d[r] = active ? (base + (size_t)((dbg_mode & 4) ? 0 : 64 * r) * rpitch)[goff] : mk<float>(0.f, 0.f);
+    for (int r = 0; r < 64; ++r) d[r] = active ? (base + (size_t)((dbg_mode & 4) ? 0 : ((dbg_mode & 8) ? 16 * r : 64 * r)) * rpitch)[goff] : mk<float>(0.f, 0.f);
     sched_fence();
 #pragma unroll
     for (int round = 0; round < 64 / kSlabs; ++round) {
@@ -110,15 +111,107 @@ __device__ __forceinline__ void res2_pair(cx<float> (&d)[64], const cx<float>* e
     }
 }
 
+// ---- the packed pair of real columns -------------------------------------------------------------
+// Columns 0 and W/2 of a half-spectrum hold real sequences.  With 2049 columns the grid would be one
+// workgroup larger than two full rounds of the chip, and that one workgroup costs a third round; so
+// the wave of column 0 carries column W/2 in its imaginary part, z = c0 + i cN, and the pointwise
+// stage takes the two spectra apart again: Z0 = (Z + Zm) / 2, ZN = -i (Z - Zm) / 2 with the mirror
+// Zm[k] = conj(Z[-k]).  Element (lane l, register r) mirrors to (lane 64 - l, register 63 - r), for
+// lane 0 to (lane 0, register 64 - r): lane 0's registers are kept in a small LDS table for that.
+__device__ __forceinline__ cx<float> mirror_of(const cx<float>& far, const cx<float>* lane0tab, int idx0, int lane, int ml) {
+    cx<float> t = mk<float>(wrow::lane_get(far.x, ml), wrow::lane_get(far.y, ml));
+    const cx<float> o = lane0tab[idx0];
+    t.x = lane == 0 ? o.x : t.x;
+    t.y = lane == 0 ? o.y : t.y;
+    return cconj(t);
+}
+__device__ __forceinline__ cx<float> half_sum(cx<float> z, cx<float> zm) { return mk<float>(0.5f * (z.x + zm.x), 0.5f * (z.y + zm.y)); }
+__device__ __forceinline__ cx<float> half_dif_mi(cx<float> z, cx<float> zm) { return mk<float>(0.5f * (z.y - zm.y), -0.5f * (z.x - zm.x)); }  // -i (z - zm) / 2
+__device__ __forceinline__ cx<float> join(cx<float> a0, cx<float> aN) { return mk<float>(a0.x - aN.y, a0.y + aN.x); }                           // a0 + i aN
+__device__ __forceinline__ void lane0_table(const cx<float> (&d)[64], cx<float>* tab, int lane) {
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r) tab[r] = d[r];
+    }
+    wfft::wave_sync();
+}
+
+// Resolvent-mode pointwise stage of the packed pair (A: S0, B: S1): two sub-phases of 16 registers;
+// each wave sends its spectrum AND its mirror at the registers the partner is about to finish.
+// The register sets (A: 0..15 then 16..31, B: 48..63 then 32..47) are chosen so that every mirror
+// source is still unmodified when it is read.  Four workgroup barriers.
+template <int HH>
+__device__ __forceinline__ void res2_pair_packed(cx<float> (&d)[64], const cx<float>* e0col, const cx<float>* eNcol, float cK, float cD0, float cDN, float gscale,
+                                                 cx<float>* mine, cx<float>* theirs, const cx<float>* tab, int lane) {
+    const unsigned ul = (unsigned)lane;
+    const int ml = (64 - lane) & 63;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int MY = HH == 0 ? 16 * sub : (sub == 0 ? 48 : 32);
+        const int PT = HH == 0 ? (sub == 0 ? 48 : 32) : 16 * sub;
+        cx<float> e0[16], eN[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            e0[rr] = (e0col + 64 * (MY + rr))[ul];
+            eN[rr] = (eNcol + 64 * (MY + rr))[ul];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int r = PT + rr;
+            mine[rr * 64 + lane] = d[r];
+            mine[(16 + rr) * 64 + lane] = mirror_of(d[63 - r], tab, (64 - r) & 63, lane, ml);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int r = MY + rr;
+            const cx<float> X = theirs[rr * 64 + lane], Xm = theirs[(16 + rr) * 64 + lane];
+            const cx<float> Y = d[r], Ym = mirror_of(d[63 - r], tab, (64 - r) & 63, lane, ml);
+            const cx<float> P = HH == 0 ? Y : X, Pm = HH == 0 ? Ym : Xm, Q = HH == 0 ? X : Y, Qm = HH == 0 ? Xm : Ym;
+            const cx<float> P0 = half_sum(P, Pm), PN = half_dif_mi(P, Pm), Q0 = half_sum(Q, Qm), QN = half_dif_mi(Q, Qm);
+            const float g0 = gscale / (1.f + cK * (e0[rr].x * e0[rr].x + e0[rr].y * e0[rr].y) + cD0);
+            const float gN = gscale / (1.f + cK * (eN[rr].x * eN[rr].x + eN[rr].y * eN[rr].y) + cDN);
+            const cx<float> U0 = (P0 + mulc(Q0, e0[rr])) * g0, UN = (PN + mulc(QN, eN[rr])) * gN;
+            const cx<float> U = join(U0, UN), V = join(e0[rr] * U0, eN[rr] * UN);
+            d[r] = HH == 0 ? U : V;
+            theirs[rr * 64 + lane] = HH == 0 ? V : U;
+            asm volatile("" : "+v"(d[r].x), "+v"(d[r].y));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) d[PT + rr] = mine[rr * 64 + lane];
+    }
+}
+
+// Multiplier-mode pointwise stage of the packed pair: Z' = scale (m0 Z0 + i mN ZN), register pairs (r, 63 - r).
+__device__ __forceinline__ void mul_packed(cx<float> (&d)[64], const cx<float>* e0col, const cx<float>* eNcol, int conj_mult, float scale, const cx<float>* tab, int lane) {
+    const unsigned ul = (unsigned)lane;
+    const int ml = (64 - lane) & 63;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const int q = 63 - r;
+        const cx<float> a0 = (e0col + 64 * r)[ul], aN = (eNcol + 64 * r)[ul], b0 = (e0col + 64 * q)[ul], bN = (eNcol + 64 * q)[ul];
+        const cx<float> Zr = d[r], Zq = d[q];
+        const cx<float> Zrm = mirror_of(Zq, tab, (64 - r) & 63, lane, ml), Zqm = mirror_of(Zr, tab, (64 - q) & 63, lane, ml);
+        const cx<float> r0 = half_sum(Zr, Zrm), rN = half_dif_mi(Zr, Zrm), q0 = half_sum(Zq, Zqm), qN = half_dif_mi(Zq, Zqm);
+        d[r] = join(conj_mult ? mulc(r0, a0) : r0 * a0, conj_mult ? mulc(rN, aN) : rN * aN) * scale;
+        d[q] = join(conj_mult ? mulc(q0, b0) : q0 * b0, conj_mult ? mulc(qN, bN) : qN * bN) * scale;
+        asm volatile("" : "+v"(d[r].x), "+v"(d[r].y), "+v"(d[q].x), "+v"(d[q].y));
+    }
+}
+
 // MODE: COL_RES2 (eight waves: four columns of S0 and of S1) or COL_MUL (four waves: four columns of S0)
-template <int MODE>
+template <int MODE, bool PACKED>
 __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Args a) {
     extern __shared__ __align__(16) float tiles[];
     constexpr int NT = MODE == COL_RES2 ? 512 : 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), h = wv >> 2, wq = wv & 3;  // wave-uniform, in scalar registers
     const int cs = a.lay.cs, C = 1 << cs;
-    const int nq = (a.Wh + 3) >> 2;                  // quarter tiles with at least one valid column (tiles are 16 wide: 4 per tile)
+    const int ncol = a.Wh - (PACKED ? 1 : 0);        // columns with a wave of their own
+    const int nq = (ncol + 3) >> 2;                  // quarter tiles with at least one such column (tiles are 16 wide: 4 per tile)
     // block -> (plane, tile, quarter of the tile): the four workgroups of a tile get indices 8 apart
     const int per_plane = 32 * ((a.lay.ntile + 7) / 8);
     const int plane = blockIdx.x / per_plane;
@@ -134,9 +227,13 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
     }
     __syncthreads();
     const int k2q = quarter << 2;                    // first column of the quarter
-    const int ncols = min(4, a.Wh - k2q);
+    const int ncols = min(4, ncol - k2q);
     const int k2 = k2q + wq;                         // this wave's column
-    const bool cvalid = k2 < a.Wh;
+    const bool cvalid = k2 < ncol;
+    const bool packed = PACKED && k2 == 0;           // this wave carries column W/2 in its imaginary part
+    const int kN = a.Wh - 1;
+    const size_t nbase = opaque(((((size_t)plane * a.lay.ntile + (kN >> cs)) * a.lay.H) << cs) + (kN & (C - 1)));
+    cx<float>* const l0tab = reinterpret_cast<cx<float>*>(tiles + (size_t)(NT / 64) * WFFT_TILE_FLOATS) + 64 * h;
     cx<float>* const Sarr = (MODE == COL_RES2 && h == 1) ? a.S1 : a.S0;
     const size_t qbase = opaque(((((size_t)plane * a.lay.ntile + (k2q >> cs)) * a.lay.H) << cs) + (k2q & (C - 1)));
     cx<float>* const stg = reinterpret_cast<cx<float>*>(tiles + (size_t)(4 * h) * WFFT_TILE_FLOATS);
@@ -144,8 +241,14 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
 
 #define DDN_CSTAMP(i) if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + (i)] = clock64();
     DDN_CSTAMP(0)
+    if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 6] = wall_clock64();
     cx<float> d[64];
     load_quarter(d, Sarr + qbase, C, stg, wq, lane, true, a.dbg_mode);
+    if (packed) {
+        const unsigned noff = (unsigned)(lane << cs);
+#pragma unroll
+        for (int r = 0; r < 64; ++r) d[r].y = (Sarr + nbase + ((size_t)(64 * r) << cs))[noff].x;
+    }
     pin(d);
     DDN_CSTAMP(1)
     wfft::fft4096<false>(d, a.wtw, mytile, lane);
@@ -159,10 +262,28 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
         const float cDd = a.cD * a.ed2[cvalid ? k2 : 0];
         cx<float>* const mine = reinterpret_cast<cx<float>*>(mytile);
         cx<float>* const theirs = reinterpret_cast<cx<float>*>(tiles + (size_t)(wv ^ 4) * WFFT_TILE_FLOATS);
-        if (h == 0) res2_pair<0>(d, ecol, a.cK, cDd, a.gscale, mine, theirs, lane, a.dbg_mode);
+        if (PACKED && quarter == 0) {
+            // the workgroup of column 0: four barriers for everybody
+            if (packed) {
+                const cx<float>* const eNcol = a.eKc + (size_t)kN * kColPitch;
+                const float cDN = a.cD * a.ed2[kN];
+                lane0_table(d, l0tab, lane);
+                if (h == 0) res2_pair_packed<0>(d, ecol, eNcol, a.cK, cDd, cDN, a.gscale, mine, theirs, l0tab, lane);
+                else res2_pair_packed<1>(d, ecol, eNcol, a.cK, cDd, cDN, a.gscale, mine, theirs, l0tab, lane);
+            } else {
+                if (h == 0) res2_pair<0>(d, ecol, a.cK, cDd, a.gscale, mine, theirs, lane, 0);
+                else res2_pair<1>(d, ecol, a.cK, cDd, a.gscale, mine, theirs, lane, 0);
+                __syncthreads();
+                __syncthreads();
+            }
+        } else if (h == 0) res2_pair<0>(d, ecol, a.cK, cDd, a.gscale, mine, theirs, lane, a.dbg_mode);
         else res2_pair<1>(d, ecol, a.cK, cDd, a.gscale, mine, theirs, lane, a.dbg_mode);
     } else {
         const unsigned ul = (unsigned)lane;
+        if (packed) {
+            lane0_table(d, l0tab, lane);
+            mul_packed(d, ecol, a.eKc + (size_t)kN * kColPitch, a.conj_mult, a.scale, l0tab, lane);
+        } else
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             cx<float> e[32];
@@ -184,9 +305,24 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
     pin(d);
     DDN_CSTAMP(4)
     __syncthreads();  // every wave is done with its tile before the tiles become staging space
+    float ny[64];
+    if (packed) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            ny[r] = d[r].y;
+            d[r].y = 0.f;
+        }
+    }
     // offsets recomputed here: keeping the 64 load addresses alive across the kernel would spill them
     store_quarter(d, Sarr + opaque(qbase), C, stg, wq, lane, true, ncols);
+    if (packed) {
+        const unsigned noff = (unsigned)(lane << cs);
+        cx<float>* const ncolp = Sarr + opaque(nbase);
+#pragma unroll
+        for (int r = 0; r < 64; ++r) (ncolp + ((size_t)(64 * r) << cs))[noff] = mk<float>(ny[r], 0.f);
+    }
     DDN_CSTAMP(5)
+    if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 7] = wall_clock64();
 #undef DDN_CSTAMP
 }
 

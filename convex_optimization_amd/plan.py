@@ -141,7 +141,7 @@ class Plan:
         return out
 
     def enable_timing(self, on=True):
-        L.check(L.lib().ddn_plan_enable_timing(self._h, 1 if on else 0))
+        L.check(L.lib().ddn_plan_enable_timing(self._h, int(on)))
 
     def last_timing(self):
         r, c = C.c_double(0), C.c_double(0)

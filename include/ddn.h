@@ -172,6 +172,8 @@ int ddn_pddr_run(ddn_plan* p, void* p_dev, void* q_dev, const void* b_dev,
  * events on the plan's stream, of the last *_run call's dominant kernel (the fused
  * row kernel) and of all its kernels; synchronises the stream. */
 int ddn_plan_last_timing(ddn_plan* p, double* row_kernel_ms_avg, double* col_kernel_ms_avg, int* n_row_launches, int* n_col_launches);
+/* on = 0: off; 1: every launch; n > 1: every n-th row launch and every n-th column launch (events cost a few
+ * microseconds each, which matters when an iteration is a few hundred). */
 int ddn_plan_enable_timing(ddn_plan* p, int on);
 
 /* Diagnostic (no counterpart in the reference): when the environment variable DDN_DEBUG_STAMPS=1 was

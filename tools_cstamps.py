@@ -19,6 +19,7 @@ torch.cuda.synchronize()
 buf = np.zeros((8192, 16), dtype=np.int64)
 L.check(lib.ddn_plan_debug_stamps(ops.plan._h, buf.ctypes.data_as(C.c_void_p), 8192))
 c = buf[4096:4096 + 544, :6]
+w = buf[4096:4096 + 544, 6:8]
 ok = c[:, 5] > 0
 print("column workgroups with stamps:", ok.sum())
 t0 = c[ok, 0].min()
@@ -31,3 +32,20 @@ print("end:   min/median/max", en.min(), np.median(en), en.max())
 print("per-WG total median", np.median(en - st_))
 order = np.argsort(st_)
 print("starts (sorted, every 32nd):", st_[order][::32])
+
+wk = w[ok]
+w0 = wk[:, 0].min()
+ws = (wk[:, 0] - w0) / 100.0
+we = (wk[:, 1] - w0) / 100.0
+print("wall-clock (us, 100 MHz counter): kernel span", we.max())
+o = np.argsort(ws)
+print("start times sorted, every 32nd:", np.round(ws[o][::32], 1))
+print("end times sorted, every 32nd:  ", np.round(np.sort(we)[::32], 1))
+idx = np.nonzero(ok)[0]
+print("slowest WGs (block, start, end):", [(int(idx[i]), round(ws[i], 1), round(we[i], 1)) for i in np.argsort(-we)[:6]])
+print("block 0 (packed pair):", round(ws[0], 1), round(we[0], 1))
+print("WGs starting <5us:", int((ws < 5).sum()), " 5..100us:", int(((ws >= 5) & (ws < 100)).sum()), " >=100us:", int((ws >= 100).sum()))
+print("second-round starts histogram (us):", np.histogram(ws[(ws >= 5)], bins=[5, 60, 70, 72, 74, 76, 80, 100, 120, 200])[0])
+print("block 0 phases (ticks):", np.diff(c[0]).tolist())
+print("block 8 phases (ticks):", np.diff(c[8]).tolist())
+print("last block phases (ticks):", np.diff(c[idx[np.argmax(we)]]).tolist())

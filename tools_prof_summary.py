@@ -10,7 +10,7 @@ def short(n):
             if 'PdrP' in n: tag += '<pdr>'
             elif 'PddrP' in n: tag += '<pddr>'
             elif 'AdmmP' in n: tag += '<admm>'
-            if k == 'k_wave_col': tag += '<res2>' if 'Li0E' in n or '<0>' in n else '<mul>'
+            if k == 'k_wave_col': tag += '<res2>' if ('ILi0E' in n or '<0,' in n) else '<mul>'
             if k in ('k_wave_row', 'k_wave_cp'):
                 import re
                 m = re.search(r'(Lb[01]ELb[01]E|Li[01]ELb[01]ELb[01]E)', n)

@@ -152,6 +152,8 @@ struct ddn_plan {
     // device buffers (typed by dtype)
     void* twW = nullptr;
     void* wtw = nullptr;     // per-lane twiddles of the register-resident 4096-point transform (float) or null
+    void* nyqd = nullptr;    // dense home of spectral column W/2 while a solver loop runs on the wave kernels
+    bool nyqd_on = false;
     void* eKc = nullptr;     // column-major natural-order copies of eK and G for the wave-per-column stage
     void* Gcm = nullptr;
     bool eKc_ok = false, Gcm_ok = false;
@@ -414,6 +416,7 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
             // experimental: columns 0 and W/2 share one wave (exact, but its workgroup is slower than a plain one)
             w.nyq_packed = (p->W % 2 == 0 && getenv("DDN_NYQ_PACK")) ? 1 : 0;
             w.conj_mult = conj_mult; w.scale = (float)scale; w.lf = lf;
+            w.nyqd = p->nyqd_on ? (float*)p->nyqd : nullptr;
             w.dbg = p->dbg ? p->dbg + 4096 * 16 : nullptr;  // second half of the stamp buffer
             w.dbg_mode = getenv("DDN_DEBUG_CMODE") ? atoi(getenv("DDN_DEBUG_CMODE")) : 0;
             TimerScope ts(p, false);
@@ -520,6 +523,7 @@ RowCommon<T> row_common(ddn_plan* p, int V, bool consume, bool produce) {
     c.H = p->H; c.W = p->W; c.batch = p->batch;
     c.V_groups = V ? p->W / V : 0;
     c.wtw = (const cx<T>*)p->wtw;
+    c.nyqd = p->nyqd_on ? (T*)p->nyqd : nullptr;
     c.fw = p->fw;
     c.lay = layout_of(p);
     c.twW = (const cx<T>*)p->twW;
@@ -707,6 +711,19 @@ int set_resolvent_impl(ddn_plan* p, double cK, double cD, const void* M_dev, int
     return DDN_OK;
 }
 
+// While a solver loop runs entirely on the wave kernels, spectral column W/2 lives in a dense side
+// array instead of the last tile (where it would use 8 bytes of every 128-byte line).
+struct NyqDense {
+    ddn_plan* p;
+    NyqDense(ddn_plan* p_, bool wave_rows) : p(p_) {
+        p->nyqd_on = false;
+        if (!wave_rows || !wcol_ready(p) || p->W % 2 || (p->Wh & 3) != 1 || getenv("DDN_NO_NYQ_DENSE")) return;
+        if (!p->nyqd && hipMalloc(&p->nyqd, sizeof(float) * 2 * (size_t)p->batch * p->H) != hipSuccess) { p->nyqd = nullptr; return; }
+        p->nyqd_on = true;
+    }
+    ~NyqDense() { p->nyqd_on = false; }
+};
+
 // ----------------------------------------------------------------------------- solver loops
 template <typename T>
 int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, double rho, double gamma, int objective, int n_iters,
@@ -716,6 +733,7 @@ int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, doubl
     RowCfg cfg;
     const bool al = aligned16(z1) && aligned16(z2) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    NyqDense nyq_guard(p, cfg.V == 0);
     typename PdrP<T>::Args a;
     RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
@@ -746,6 +764,7 @@ int pddr_run_impl(ddn_plan* p, void* pp, void* q, const void* b, double t, doubl
     RowCfg cfg;
     const bool al = aligned16(pp) && aligned16(q) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    NyqDense nyq_guard(p, cfg.V == 0);
     typename PddrP<T>::Args a;
     RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
@@ -777,6 +796,7 @@ int admm_run_impl(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b
     RowCfg cfg;
     const bool al = aligned16(u) && aligned16(w) && aligned16(y) && aligned16(z) && aligned16(b) && aligned16(sol) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    NyqDense nyq_guard(p, cfg.V == 0);
     typename AdmmP<T>::Args a;
     RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
@@ -820,6 +840,7 @@ int cp_run_impl(ddn_plan* p, void* x, void* z, void* y, const void* b, double t,
     RowCfg cfg;
     const bool al = aligned16(x) && aligned16(z) && aligned16(y) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * ((p->H + 1) / 2), cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    NyqDense nyq_guard(p, cfg.V == 0);
     CpArgs<T> a;
     RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
@@ -932,7 +953,7 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
 
 int ddn_plan_destroy(ddn_plan* p) {
     if (!p) return DDN_OK;
-    void* bufs[] = {p->twW, p->wtw, p->eKc, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
+    void* bufs[] = {p->twW, p->wtw, p->nyqd, p->eKc, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : p->ev_pool) {

@@ -430,6 +430,7 @@ struct RowCommon {
     SpecLayout lay;
     const cx<T>* twW;    // global twiddle tables for W
     const cx<T>* wtw;    // per-lane twiddles of the wave-per-row kernels ([64][16]) or null
+    T* nyqd;             // dense home of spectral column W/2 (real parts, [batch][2 arrays][H]) or null = inside the tiles
     cx<T>* S0;
     cx<T>* S1;
     const cx<T>* eDrow;  // row-spectral D table (W/2+1 entries) or null = 2-tap stencils

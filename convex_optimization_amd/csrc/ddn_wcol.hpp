@@ -239,11 +239,18 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
     cx<float>* const stg = reinterpret_cast<cx<float>*>(tiles + (size_t)(4 * h) * WFFT_TILE_FLOATS);
     float* const mytile = tiles + (size_t)wv * WFFT_TILE_FLOATS;
 
+    // column W/2 with a dense home: its quarter holds nothing else, so the workgroup skips the tile traffic
+    // (the column would use 8 bytes of every 128-byte line) and wave 0 of each half streams the dense array
+    const bool dense = !PACKED && a.nyqd && (a.Wh & 3) == 1 && k2q == a.Wh - 1;
+    float* const dcol = a.nyqd + ((size_t)plane * 2 + h) * 4096;
 #define DDN_CSTAMP(i) if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + (i)] = clock64();
     DDN_CSTAMP(0)
     if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 6] = wall_clock64();
     cx<float> d[64];
-    load_quarter(d, Sarr + qbase, C, stg, wq, lane, true, a.dbg_mode);
+    if (dense) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r) d[r] = mk<float>(wq == 0 ? dcol[64 * r + lane] : 0.f, 0.f);
+    } else load_quarter(d, Sarr + qbase, C, stg, wq, lane, true, a.dbg_mode);
     if (packed) {
         const unsigned noff = (unsigned)(lane << cs);
 #pragma unroll
@@ -314,7 +321,12 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
         }
     }
     // offsets recomputed here: keeping the 64 load addresses alive across the kernel would spill them
-    store_quarter(d, Sarr + opaque(qbase), C, stg, wq, lane, true, ncols);
+    if (dense) {
+        if (wq == 0) {
+#pragma unroll
+            for (int r = 0; r < 64; ++r) dcol[64 * r + lane] = d[r].x;
+        }
+    } else store_quarter(d, Sarr + opaque(qbase), C, stg, wq, lane, true, ncols);
     if (packed) {
         const unsigned noff = (unsigned)(lane << cs);
         cx<float>* const ncolp = Sarr + opaque(nbase);

@@ -19,6 +19,7 @@ struct Args {
     const cx<float>* wtw;  // per-lane twiddles of the 4096-point transform
     SpecLayout lay;
     int Wh, batch;
+    float* nyqd;           // dense home of column W/2 (real parts, [batch][2 arrays][H]) or null = inside the last tile
     int nyq_packed;        // W even: column W/2 (real-valued, like column 0) rides in the imaginary part of column 0
     int conj_mult;
     float scale;

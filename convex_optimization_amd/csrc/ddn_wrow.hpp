@@ -60,14 +60,15 @@ __device__ __forceinline__ size_t spec_row_base(const SpecLayout& l, int plane, 
 // Merge: half-spectra A = F(a), B = F(b), k = 0..2048, of two real rows -> spectrum of a + i b.
 // rowA / rowB: the arrays already offset to the row (uniform); TWO = false: b = 0.
 template <bool TWO>
-__device__ __forceinline__ void pack(cx<float> (&d)[64], const cx<float>* rowA, const cx<float>* rowB, const SpecAddr& sa, int lane) {
+__device__ __forceinline__ void pack(cx<float> (&d)[64], const cx<float>* rowA, const cx<float>* rowB, const SpecAddr& sa, int lane, const float* nyqA = nullptr, const float* nyqB = nullptr) {
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
         d[r] = (rowA + r * sa.rstride)[sa.lane_off];                         // A[k], k = 64 r + lane
         d[63 - r] = TWO ? (rowB + r * sa.rstride)[sa.lane_off] : mk<float>(0.f, 0.f);  // B[k]
     }
-    const cx<float> Un = rowA[sa.nyq];
-    const cx<float> Vn = TWO ? rowB[sa.nyq] : mk<float>(0.f, 0.f);
+    // column W/2 (real): from its dense home when there is one, else from the last tile
+    const cx<float> Un = nyqA ? mk<float>(*nyqA, 0.f) : rowA[sa.nyq];
+    const cx<float> Vn = TWO ? (nyqB ? mk<float>(*nyqB, 0.f) : rowB[sa.nyq]) : mk<float>(0.f, 0.f);
     sched_fence();
     const int ml = (64 - lane) & 63;
     const float u0 = d[0].x, v0 = d[63].x;
@@ -94,7 +95,7 @@ __device__ __forceinline__ void pack(cx<float> (&d)[64], const cx<float>* rowA, 
 
 // Split: spectrum Z of a + i b -> half-spectra of a (to rowA) and b (to rowB when TWO).
 template <bool TWO>
-__device__ __forceinline__ void unpack(const cx<float> (&d)[64], cx<float>* rowA, cx<float>* rowB, const SpecAddr& sa, int lane) {
+__device__ __forceinline__ void unpack(const cx<float> (&d)[64], cx<float>* rowA, cx<float>* rowB, const SpecAddr& sa, int lane, float* nyqA = nullptr, float* nyqB = nullptr) {
     const int ml = (64 - lane) & 63;
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
@@ -107,8 +108,10 @@ __device__ __forceinline__ void unpack(const cx<float> (&d)[64], cx<float>* rowA
         if (TWO) (rowB + r * sa.rstride)[sa.lane_off] = mk<float>(0.5f * (Z.y + Zm.y), 0.5f * (Zm.x - Z.x));
     }
     if (lane == 0) {
-        rowA[sa.nyq] = mk<float>(d[32].x, 0.f);
-        if (TWO) rowB[sa.nyq] = mk<float>(d[32].y, 0.f);
+        if (nyqA) *nyqA = d[32].x; else rowA[sa.nyq] = mk<float>(d[32].x, 0.f);
+        if (TWO) {
+            if (nyqB) *nyqB = d[32].y; else rowB[sa.nyq] = mk<float>(d[32].y, 0.f);
+        }
     }
 }
 
@@ -139,7 +142,7 @@ __device__ __forceinline__ A at_reg(const A& a, int r) {
 // ----------------------------------------------------------------------------------------------
 // PDR / PDDR / ADMM: the policies of ddn_kernels.hpp, one pixel per register.
 // PD = depth of the iterate-array load pipeline (registers r .. r+PD-1 are in flight).
-template <class P, int PD, bool CONS, bool PROD>
+template <class P, int PD, bool CONS, bool PROD, int FE = 1>
 #ifndef WROW_MINW
 #define WROW_MINW 2
 #endif
@@ -157,9 +160,11 @@ __global__ void __launch_bounds__(64, WROW_MINW) k_wave_row(RowCommon<float> c, 
         cx<float>* const row0 = c.S0 + sbase;
         cx<float>* const row1 = c.S1 + sbase;
         const unsigned ul = (unsigned)lane;
+        float* const nq0 = c.nyqd ? c.nyqd + ((size_t)plane * 2 * c.H + (row - plane * c.H)) : nullptr;
+        float* const nq1 = c.nyqd ? nq0 + c.H : nullptr;
         cx<float> d[64];
         if (CONS) {
-            pack<true>(d, row0, row1, sa, lane);
+            pack<true>(d, row0, row1, sa, lane, nq0, nq1);
             wfft::fft4096<true>(d, c.wtw, tile, lane);
             pin(d);
         } else {
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__(64, WROW_MINW) k_wave_row(RowCommon<float> c, 
         float rs_first = 0.f, rs_prev = 0.f;
 #pragma unroll
         for (int r = 0; r < 64; ++r) {
-            sched_fence();
+            if (r % FE == 0) sched_fence();  // FE: pixel registers the scheduler may interleave
             float u[1] = {d[r].x}, k[1] = {d[r].y}, du[1], re[1], im[1], s[1];
             const float rot = from_prev_lane(u[0]);
             du[0] = u[0] - (lane == 0 ? rot_prev : rot);
@@ -208,7 +213,7 @@ __global__ void __launch_bounds__(64, WROW_MINW) k_wave_row(RowCommon<float> c, 
             sched_fence();
             wfft::fft4096<false>(d, c.wtw, tile, lane);
             pin(d);
-            unpack<true>(d, row0, row1, sa, lane);
+            unpack<true>(d, row0, row1, sa, lane, nq0, nq1);
         }
     }
 }
@@ -320,10 +325,12 @@ __global__ void __launch_bounds__(64, 2) k_wave_cp(RowCommon<float> c, CpArgs<fl
         advance(a1, opaque((row0 + 1) * 4096));
         cx<float>* const rw0 = c.S0 + opaque(sb0);
         cx<float>* const rw1 = c.S0 + opaque(sb1);
+        float* const nqa = c.nyqd ? c.nyqd + ((size_t)plane * 2 * H + r0) : nullptr;
+        float* const nqb = c.nyqd ? nqa + 1 : nullptr;
         cx<float> d[64];
         if (CONS) {
-            if (two) pack<true>(d, rw0, rw1, sa, lane);
-            else pack<false>(d, rw0, nullptr, sa, lane);
+            if (two) pack<true>(d, rw0, rw1, sa, lane, nqa, nqb);
+            else pack<false>(d, rw0, nullptr, sa, lane, nqa, nullptr);
             wfft::fft4096<true>(d, c.wtw, tile, lane);
             pin(d);
         } else {
@@ -363,8 +370,8 @@ __global__ void __launch_bounds__(64, 2) k_wave_cp(RowCommon<float> c, CpArgs<fl
             sched_fence();
             wfft::fft4096<false>(d, c.wtw, tile, lane);
             pin(d);
-            if (two) unpack<true>(d, rw0, rw1, sa, lane);
-            else unpack<false>(d, rw0, nullptr, sa, lane);
+            if (two) unpack<true>(d, rw0, rw1, sa, lane, nqa, nqb);
+            else unpack<false>(d, rw0, nullptr, sa, lane, nqa, nullptr);
         }
     }
 }

@@ -341,6 +341,44 @@ def test_height_4096_wave_columns_vs_oracle(pkg, golden_dir):
         assert np.array_equal(xb[i].numpy(), xi.numpy())
 
 
+def test_full_size_4096_square_vs_oracle_and_tile_path(pkg, golden_dir, monkeypatch):
+    """BASELINE config 3 size (4096 x 4096, motion blur): the solver loops run on the wave-per-row and
+    wave-per-column kernels with spectral column W/2 in its dense side array.  Two iterations of every
+    solver against the CPU oracle, and five iterations bit-for-bit against the same kernels with that
+    column left inside the tiles (the two homes hold the same numbers)."""
+    import os
+    k = _load(golden_dir, "kernels.npz")
+    kern = torch.from_numpy(k["motion15_45"])
+    H = W = 4096
+    torch.manual_seed(0)
+    img = torch.rand(1, H, W)
+    b = O.circular_convolve2d(img, kern)[0]
+    torch.manual_seed(7)
+    st = (torch.rand(H, W), torch.rand(H, W), torch.rand(3, H, W))
+    stA = tuple(torch.clamp(torch.randn(s, dtype=torch.float32), 0, 1) for s in [(H, W), (H, W), (3, H, W), (3, H, W)])
+    stP = (torch.rand(H, W), torch.rand(3, H, W))
+
+    def run_all(n):
+        return [pkg.chambolle_pock_solver(b[None], kern, max_iter=n + 1, init_state=st),
+                pkg.admm_solver(b, "l1", kernel=kern, niters=n + 1, tol=-1.0, init_state=stA),
+                pkg.primal_dr_splitting("l1", kern, b, niters=n, loss_function=pkg.core.mse, tol=-1.0),
+                pkg.primal_dual_dr_splitting(b, kern, niters=n + 1, init_state=stP, tol=-1.0)]
+
+    got = run_all(2)
+    ref = [O.chambolle_pock(b[None], kern, max_iter=3, init_state=st),
+           O.admm_solver(b, "l1", kernel=kern, niters=3, tol=-1.0, init_state=stA),
+           O.primal_dr_splitting("l1", kern, b, niters=2),
+           O.primal_dual_dr_splitting(b, kern, niters=3, init_state=stP)]
+    for g, r in zip(got, ref):
+        assert rel(g.numpy(), r.numpy()) < 1e-5
+    dense = run_all(5)
+    monkeypatch.setenv("DDN_NO_NYQ_DENSE", "1")
+    tiled = run_all(5)
+    monkeypatch.delenv("DDN_NO_NYQ_DENSE")
+    for g, r in zip(dense, tiled):
+        assert np.array_equal(g.numpy(), r.numpy())
+
+
 def test_batch_equals_loop_of_single_calls(pkg, golden_dir):
     k = _load(golden_dir, "kernels.npz")
     kern = k["gauss9"]

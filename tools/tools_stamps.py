@@ -1,6 +1,6 @@
 import os, sys, ctypes as C
 os.environ["DDN_DEBUG_STAMPS"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import convex_optimization_amd as pkg
 from convex_optimization_amd import _lib as L

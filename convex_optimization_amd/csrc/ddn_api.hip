@@ -239,6 +239,8 @@ bool choose_col(ddn_plan* p) {
         while ((1 << lim) < p->tune_cols) ++lim;
     }
     p->cs = std::min(c2, lim);
+    // experimental: 4-column tiles for the wave-per-column stage (every 128-byte line belongs to one column workgroup)
+    if (sizeof(T) == 4 && p->H == 4096 && p->tune_cols == 0 && getenv("DDN_TILE4")) p->cs = 2;
     p->ntile = (p->Wh + (1 << p->cs) - 1) >> p->cs;
     // tiles a power of two apart would put the rows that resident workgroups stream in lockstep at the
     // same offset modulo the DRAM channel interleave: pad the tile pitch for large power-of-two heights
@@ -384,7 +386,7 @@ inline int col_threads_for(const ddn_plan* p, int n, int cs, int narr) {
 inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
 
 inline bool wcol_ready(const ddn_plan* p) {
-    return p->eKc_ok && p->wtw && p->H == 4096 && p->cs == 4 && !p->injected && !getenv("DDN_NO_WAVE_COLS");
+    return p->eKc_ok && p->wtw && p->H == 4096 && (p->cs == 4 || p->cs == 2) && !p->injected && !getenv("DDN_NO_WAVE_COLS");
 }
 // column-major natural-order copy of a tiled multiplier (complex and / or real)
 template <typename T>
@@ -492,8 +494,10 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc) {
     const int W = p->W;
     if (sizeof(T) == 4 && p->wtw && W == 4096 && !p->injected && !getenv("DDN_NO_WAVE_ROWS")) {
         // one wavefront per row, eight per CU (256 registers each), the row held in registers
-        rc.V = 0; rc.threads = 64; rc.lds = 0;
-        rc.grid = std::max(1, std::min(work_items, p->num_cu * 8));
+        // (four rows per workgroup with 4-column spectral tiles, see ddn_wrow.hpp)
+        const int wpw = p->cs == 2 ? 4 : 1;
+        rc.V = 0; rc.threads = 64 * wpw; rc.lds = 0;
+        rc.grid = std::max(1, std::min((work_items + wpw - 1) / wpw, p->num_cu * 8 / wpw));
         return true;
     }
     if (aligned && W % 4 == 0 && W <= 4096) {
@@ -997,7 +1001,7 @@ int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
     p->have_K = true;
     p->injected = false;
     p->eKc_ok = p->Gcm_ok = false;
-    if (p->dtype == DDN_F32 && p->wtw && p->H == 4096 && p->cs == 4) {
+    if (p->dtype == DDN_F32 && p->wtw && p->H == 4096 && (p->cs == 4 || p->cs == 2)) {
         if ((rc = make_colmajor<float>(p, (const cx<float>*)p->eK, nullptr, &p->eKc, nullptr))) return rc;
         p->eKc_ok = true;
     }

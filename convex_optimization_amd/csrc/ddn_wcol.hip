@@ -15,7 +15,8 @@ static int wcol_go(hipStream_t st, int grid, const wcol::Args& a) {
 }
 
 int wcol_launch(hipStream_t st, int mode, const wcol::Args& a) {
-    const int grid = a.batch * 32 * ((a.lay.ntile + 7) / 8);
+    const int nq = (a.Wh - (a.nyq_packed ? 1 : 0) + 3) >> 2;
+    const int grid = a.batch * (a.lay.cs == 2 ? nq : 32 * ((a.lay.ntile + 7) / 8));
     if (mode == COL_RES2) return a.nyq_packed ? wcol_go<COL_RES2, true>(st, grid, a) : wcol_go<COL_RES2, false>(st, grid, a);
     return a.nyq_packed ? wcol_go<COL_MUL, true>(st, grid, a) : wcol_go<COL_MUL, false>(st, grid, a);
 }

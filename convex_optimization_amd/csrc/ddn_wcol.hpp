@@ -23,9 +23,10 @@ using wrow::pin;
 using wrow::sched_fence;
 
 
-constexpr int kSlabs = 16;                 // row slabs (of 64 rows) staged per round
+constexpr int kSlabs = 16;                 // row slabs (of 64 rows) staged per round (32 with a thinner padding measured no faster)
 constexpr int kSlabPitch = 4 * 64 + 16;    // complex elements per staged slab (row pitch padded every 4 rows)
 constexpr size_t kLdsBytes = WFFT_TILE_FLOATS * sizeof(float);  // per wave
+static_assert(kSlabs * kSlabPitch * 2 <= 4 * WFFT_TILE_FLOATS, "a round of staged slabs must fit the four tiles of a half");
 constexpr size_t kLdsExtra = 2 * 64 * sizeof(cx<float>);          // lane-0 tables of the packed pair
 
 // Row-major global <-> column-owner registers for one quarter tile (4 columns), executed by the
@@ -212,15 +213,18 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
     const int cs = a.lay.cs, C = 1 << cs;
     const int ncol = a.Wh - (PACKED ? 1 : 0);        // columns with a wave of their own
     const int nq = (ncol + 3) >> 2;                  // quarter tiles with at least one such column (tiles are 16 wide: 4 per tile)
-    // block -> (plane, tile, quarter of the tile): the four workgroups of a tile get indices 8 apart
-    const int per_plane = 32 * ((a.lay.ntile + 7) / 8);
+    // block -> (plane, quarter tile).  16-column tiles: the four workgroups of a tile get indices 8 apart;
+    // 4-column tiles: a quarter is a tile of its own, nothing is shared.
+    const int per_plane = cs == 2 ? nq : 32 * ((a.lay.ntile + 7) / 8);
     const int plane = blockIdx.x / per_plane;
     const int b = blockIdx.x - plane * per_plane;
-    const int x = b & 7, aa = b >> 3;
-    const int tile = 8 * (aa >> 2) + x, part = aa & 3;
-    const int quarter = 4 * tile + part;
-    if (a.lf.enabled && tile == 0 && part == 0) loss_finalize(a.lf, plane, reinterpret_cast<double*>(tiles), tid, NT);
-    if (tile >= a.lay.ntile || quarter >= nq) return;
+    int quarter = b;
+    if (cs != 2) {
+        const int x = b & 7, aa = b >> 3;
+        quarter = 4 * (8 * (aa >> 2) + x) + (aa & 3);
+    }
+    if (a.lf.enabled && quarter == 0) loss_finalize(a.lf, plane, reinterpret_cast<double*>(tiles), tid, NT);
+    if (quarter >= nq) return;
     if (a.lf.stop) {
         const int s = a.lf.stop[plane];
         if (s >= 0 && s < a.lf.iter) return;

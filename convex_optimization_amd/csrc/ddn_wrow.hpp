@@ -135,23 +135,34 @@ __device__ __forceinline__ void advance(AdmmP<float>::Args& a, size_t o) {
 template <class A>
 __device__ __forceinline__ A at_reg(const A& a, int r) {
     A q = a;
-    advance(q, (size_t)(64 * r));
+    // the register offset is opaque too: base + offset then stays a scalar sum and the access takes the
+    // scalar-base form (one shared lane-offset register) instead of one 64-bit address pair per array
+    advance(q, opaque((size_t)(64 * r)));
     return q;
 }
 
 // ----------------------------------------------------------------------------------------------
 // PDR / PDDR / ADMM: the policies of ddn_kernels.hpp, one pixel per register.
 // PD = depth of the iterate-array load pipeline (registers r .. r+PD-1 are in flight).
-template <class P, int PD, bool CONS, bool PROD, int FE = 1>
+template <class P, int PD, bool CONS, bool PROD, int FE = 1, int WPW = 1>
 #ifndef WROW_MINW
 #define WROW_MINW 2
 #endif
-__global__ void __launch_bounds__(64, WROW_MINW) k_wave_row(RowCommon<float> c, typename P::Args a0) {
-    __shared__ float tile[WFFT_TILE_FLOATS];
-    const int lane = threadIdx.x;
+__global__ void __launch_bounds__(64 * WPW, WROW_MINW) k_wave_row(RowCommon<float> c, typename P::Args a0) {
+    // WPW waves per workgroup, one row each.  WPW = 4 goes with 4-column spectral tiles, where a
+    // 128-byte line holds four consecutive rows of a tile: the four waves of a group then touch the
+    // same lines at the same time (one L1 fill serves all four, the L2 merges their stores).
+    extern __shared__ __align__(16) float wtiles[];
+    const int lane = threadIdx.x & 63;
+    const int wave = WPW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const tile = wtiles + (size_t)wave * WFFT_TILE_FLOATS;
     const int nrows = c.batch * c.H;
+    const int ngroups = (nrows + WPW - 1) / WPW;
     const SpecAddr sa(c.lay, lane);
-    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        if (WPW > 1) __syncthreads();
+        const int row = grp * WPW + wave;
+        if (row >= nrows) continue;
         const int plane = row / c.H;
         if (c.stop && c.stop[plane] >= 0) continue;
         typename P::Args a = a0;
@@ -307,14 +318,20 @@ __device__ __forceinline__ void cp_load_z(cx<float> (&d)[64], const CpArgs<float
 __device__ __forceinline__ void advance(CpArgs<float>& a, size_t o) { a.x += o; a.z += o; a.y0 += o; a.y1 += o; a.y2 += o; a.b += o; }
 
 
-template <int PD, int STEP, bool CONS, bool PROD>
-__global__ void __launch_bounds__(64, 2) k_wave_cp(RowCommon<float> c, CpArgs<float> a0) {
-    __shared__ float tile[WFFT_TILE_FLOATS];
-    const int lane = threadIdx.x, H = c.H;
+template <int PD, int STEP, bool CONS, bool PROD, int WPW = 1>
+__global__ void __launch_bounds__(64 * WPW, 2) k_wave_cp(RowCommon<float> c, CpArgs<float> a0) {
+    extern __shared__ __align__(16) float wtiles[];
+    const int lane = threadIdx.x & 63, H = c.H;
+    const int wave = WPW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const tile = wtiles + (size_t)wave * WFFT_TILE_FLOATS;
     const int ppp = (H + 1) >> 1;
     const int npairs = c.batch * ppp;
     const SpecAddr sa(c.lay, lane);
-    for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
+    const int ngroups = (npairs + WPW - 1) / WPW;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        if (WPW > 1) __syncthreads();
+        const int pr = grp * WPW + wave;
+        if (pr >= npairs) continue;
         const int plane = pr / ppp;
         const int r0 = (pr - plane * ppp) * 2;
         const bool two = r0 + 1 < H;

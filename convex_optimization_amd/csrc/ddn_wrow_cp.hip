@@ -1,12 +1,18 @@
-// Wave-per-row Chambolle-Pock kernels (W = 4096, float).
+// Wave-per-row Chambolle-Pock kernels (W = 4096, float); one wave (one row pair) per workgroup with
+// 16-column spectral tiles, four with 4-column tiles.
 #define DDN_WAVE_FAST 1
 #include "ddn_launch.hpp"
 #include "ddn_wrow.hpp"
+
+template <int WPW>
+static int go(hipStream_t st, int grid, const RowCommon<float>& c, const CpArgs<float>& a) {
+    const size_t lds = (size_t)WPW * WFFT_TILE_FLOATS * sizeof(float);
+    if (a.step == 0) return launch_row_fn(st, wrow::k_wave_cp<8, 0, true, true, WPW>, grid, 64 * WPW, lds, c, a);
+    if (!c.do_consume) return launch_row_fn(st, wrow::k_wave_cp<8, 1, false, true, WPW>, grid, 64 * WPW, lds, c, a);
+    if (c.do_produce) return launch_row_fn(st, wrow::k_wave_cp<8, 1, true, true, WPW>, grid, 64 * WPW, lds, c, a);
+    return launch_row_fn(st, wrow::k_wave_cp<8, 1, true, false, WPW>, grid, 64 * WPW, lds, c, a);
+}
+
 int wrow_cp_launch(hipStream_t st, int grid, const RowCommon<float>& c, const CpArgs<float>& a) {
-    if (a.step == 0) hipLaunchKernelGGL((wrow::k_wave_cp<8, 0, true, true>), dim3(grid), dim3(64), 0, st, c, a);
-    else if (!c.do_consume) hipLaunchKernelGGL((wrow::k_wave_cp<8, 1, false, true>), dim3(grid), dim3(64), 0, st, c, a);
-    else if (c.do_produce) hipLaunchKernelGGL((wrow::k_wave_cp<8, 1, true, true>), dim3(grid), dim3(64), 0, st, c, a);
-    else hipLaunchKernelGGL((wrow::k_wave_cp<8, 1, true, false>), dim3(grid), dim3(64), 0, st, c, a);
-    HIPCHK(hipGetLastError());
-    return DDN_OK;
+    return c.lay.cs == 2 ? go<4>(st, grid, c, a) : go<1>(st, grid, c, a);
 }

@@ -1,14 +1,20 @@
 // Wave-per-row pdr kernels (W = 4096, float): full iteration, consume-only (last launch) and
-// produce-only (first launch) variants.  Load-pipeline depth 8: measured best (the kernel is not
+// produce-only (first launch) variants; one wave per workgroup with 16-column spectral tiles, four
+// (rows 4g .. 4g+3) with 4-column tiles.  Load-pipeline depth 8: measured best (the kernel is not
 // latency-bound on the iterate loads; deeper pipelines only cost registers).
 #define DDN_WAVE_FAST 1
 #include "ddn_launch.hpp"
 #include "ddn_wrow.hpp"
+
+template <int WPW>
+static int go(hipStream_t st, int grid, const RowCommon<float>& c, const PdrP<float>::Args& a) {
+    const size_t lds = (size_t)WPW * WFFT_TILE_FLOATS * sizeof(float);
+    if (c.do_consume && c.do_produce) return launch_row_fn(st, wrow::k_wave_row<PdrP<float>, 8, true, true, 2, WPW>, grid, 64 * WPW, lds, c, a);
+    if (c.do_consume) return launch_row_fn(st, wrow::k_wave_row<PdrP<float>, 8, true, false, 1, WPW>, grid, 64 * WPW, lds, c, a);
+    return launch_row_fn(st, wrow::k_wave_row<PdrP<float>, 8, false, true, 1, WPW>, grid, 64 * WPW, lds, c, a);
+}
+
 template <>
 int wrow_launch<PdrP<float>>(hipStream_t st, int grid, const RowCommon<float>& c, const PdrP<float>::Args& a) {
-    if (c.do_consume && c.do_produce) hipLaunchKernelGGL((wrow::k_wave_row<PdrP<float>, 8, true, true, 2>), dim3(grid), dim3(64), 0, st, c, a);
-    else if (c.do_consume) hipLaunchKernelGGL((wrow::k_wave_row<PdrP<float>, 8, true, false>), dim3(grid), dim3(64), 0, st, c, a);
-    else hipLaunchKernelGGL((wrow::k_wave_row<PdrP<float>, 8, false, true>), dim3(grid), dim3(64), 0, st, c, a);
-    HIPCHK(hipGetLastError());
-    return DDN_OK;
+    return c.lay.cs == 2 ? go<4>(st, grid, c, a) : go<1>(st, grid, c, a);
 }

@@ -58,6 +58,21 @@ def ssim(x: torch.Tensor, y: torch.Tensor, window_size: int = 11, max_val: float
     x, y = to4(x), to4(y)
     if x.shape != y.shape:
         raise ValueError(f"Input tensors must have the same shape, got {x.shape} and {y.shape}")
+    if x.is_cuda and y.is_cuda and window_size == 11 and x.dtype == y.dtype and x.dtype in (torch.float32, torch.float64):
+        # fused device kernel (ddn_ssim): one pass over the two images
+        import ctypes as C
+        from ..plan import _ptr
+        B, nc, H, W = x.shape
+        xc, yc = x.contiguous(), y.contiguous()
+        out = torch.empty((B * nc,), dtype=torch.float64, device=x.device)
+        co_ = torch.arange(window_size, dtype=torch.float32) - window_size // 2      # loss.py:75-81, on the host
+        g_ = torch.exp(-(co_ ** 2) / (2 * 1.5 ** 2))
+        g_ = (g_ / g_.sum()).contiguous()
+        g11 = (C.c_float * 11)(*g_.tolist())
+        with torch.cuda.device(x.device):
+            L.check(L.lib().ddn_ssim(L.F64 if x.dtype == torch.float64 else L.F32, _ptr(xc), _ptr(yc), H, W, B * nc, float(max_val), g11, _ptr(out),
+                                     C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return out.view(B, nc).mean(dim=1).to(x.dtype)
     C1, C2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
     co = torch.arange(window_size, dtype=torch.float32) - window_size // 2
     g = torch.exp(-(co ** 2) / (2 * 1.5 ** 2))

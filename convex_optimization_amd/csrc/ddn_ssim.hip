@@ -1,0 +1,149 @@
+// Fused SSIM (core/loss.py:39-110 of the reference): 11 x 11 Gaussian window (sigma 1.5, zero padding)
+// applied to x, y, x*x, y*y, x*y, the SSIM map and its mean, in one pass over the two images.
+// A workgroup produces a 16 x 64 tile of the map: it stages the (16+10) x (64+10) input patch of both
+// images in LDS, runs the horizontal taps of the five maps into LDS, then the vertical taps per output
+// pixel, and sums the map in double.  The window is separable (the reference builds it as an outer
+// product); per image the partial sums are reduced in a fixed order by a second kernel.
+#include "ddn_launch.hpp"
+
+namespace {
+
+constexpr int TH = 16, TW = 64, R = 5, PH = TH + 2 * R, PW = TW + 2 * R;
+
+struct SsimWin {
+    float g[11];       // separable factor (float path)
+    float w2[121];     // the reference's window: float32(g[i] * g[j]) (double path, tap for tap)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_ssim_tile(const T* x, const T* y, int H, int W, int tiles_x, int tiles_y, SsimWin win, double c1, double c2, double* partial) {
+    __shared__ T sx[PH][PW + 1], sy[PH][PW + 1];
+    __shared__ T hm[5][PH][TW + 1];
+    __shared__ double red[64];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int plane = b / tiles_y;
+    const T* xp = x + (size_t)plane * H * W;
+    const T* yp = y + (size_t)plane * H * W;
+    const int r0 = ty * TH - R, c0 = tx * TW - R;
+    for (int i = tid; i < PH * PW; i += 256) {
+        const int pr = i / PW, pc = i - pr * PW;
+        const int r = r0 + pr, c = c0 + pc;
+        const bool in = r >= 0 && r < H && c >= 0 && c < W;
+        sx[pr][pc] = in ? xp[(size_t)r * W + c] : (T)0;
+        sy[pr][pc] = in ? yp[(size_t)r * W + c] : (T)0;
+    }
+    __syncthreads();
+    if constexpr (sizeof(T) == 8) {
+        // float64: the reference's window is the float32-rounded outer product, which is not exactly
+        // separable; evaluate its 121 taps as they are (parity to 1e-11; not a performance path)
+        double acc2 = 0;
+        for (int i = tid; i < TH * TW; i += 256) {
+            const int orow = i / TW, oc = i - orow * TW;
+            const int r = ty * TH + orow, c = tx * TW + oc;
+            if (r < H && c < W) {
+                T m[5] = {0, 0, 0, 0, 0};
+                for (int u = 0; u < 11; ++u)
+#pragma unroll
+                    for (int v = 0; v < 11; ++v) {
+                        const T g = (T)win.w2[u * 11 + v];
+                        const T vx = sx[orow + u][oc + v], vy = sy[orow + u][oc + v];
+                        m[0] += g * vx; m[1] += g * vy; m[2] += g * (vx * vx); m[3] += g * (vy * vy); m[4] += g * (vx * vy);
+                    }
+                const T mux = m[0], muy = m[1];
+                const T vx = m[2] - mux * mux, vy = m[3] - muy * muy, cxy = m[4] - mux * muy;
+                const T num = ((T)2 * mux * muy + (T)c1) * ((T)2 * cxy + (T)c2);
+                const T den = (mux * mux + muy * muy + (T)c1) * (vx + vy + (T)c2);
+                acc2 += (double)(num / den);
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) acc2 += __shfl_xor(acc2, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = acc2;
+        __syncthreads();
+        if (tid == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        return;
+    }
+    // horizontal taps: PH x TW outputs of five maps
+    for (int i = tid; i < PH * TW; i += 256) {
+        const int pr = i / TW, oc = i - pr * TW;
+        T a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const T g = (T)win.g[k];
+            const T vx = sx[pr][oc + k], vy = sy[pr][oc + k];
+            a0 += g * vx;
+            a1 += g * vy;
+            a2 += g * (vx * vx);
+            a3 += g * (vy * vy);
+            a4 += g * (vx * vy);
+        }
+        hm[0][pr][oc] = a0; hm[1][pr][oc] = a1; hm[2][pr][oc] = a2; hm[3][pr][oc] = a3; hm[4][pr][oc] = a4;
+    }
+    __syncthreads();
+    double acc = 0;
+    for (int i = tid; i < TH * TW; i += 256) {
+        const int orow = i / TW, oc = i - orow * TW;
+        const int r = ty * TH + orow, c = tx * TW + oc;
+        if (r < H && c < W) {
+            T m[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const T g = (T)win.g[k];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) m[q] += g * hm[q][orow + k][oc];
+            }
+            const T mux = m[0], muy = m[1];
+            const T vx = m[2] - mux * mux, vy = m[3] - muy * muy, cxy = m[4] - mux * muy;
+            const T num = ((T)2 * mux * muy + (T)c1) * ((T)2 * cxy + (T)c2);
+            const T den = (mux * mux + muy * muy + (T)c1) * (vx + vy + (T)c2);
+            acc += (double)(num / den);
+        }
+    }
+    // workgroup sum in a fixed order
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void k_ssim_final(const double* partial, int per_plane, double npix, double* out) {
+    __shared__ double red[256];
+    const int plane = blockIdx.x, tid = threadIdx.x;
+    double a = 0;
+    for (int i = tid; i < per_plane; i += 256) a += partial[(size_t)plane * per_plane + i];
+    red[tid] = a;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) out[plane] = red[0] / npix;
+}
+
+}  // namespace
+
+extern "C" int ddn_ssim(int dtype, const void* x, const void* y, int H, int W, int planes, double max_val, const float* g11_host, double* out_dev, void* stream) {
+    if (!x || !y || !out_dev || !g11_host || H < 1 || W < 1 || planes < 1) return fail(DDN_E_ARG, "ssim: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    SsimWin win;
+    for (int i = 0; i < 11; ++i) win.g[i] = g11_host[i];
+    for (int i = 0; i < 11; ++i)
+        for (int j = 0; j < 11; ++j) win.w2[i * 11 + j] = g11_host[i] * g11_host[j];  // float32 product, as g[:, None] * g[None, :]
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int per_plane = tiles_x * tiles_y;
+    double* part = nullptr;
+    HIPCHK(hipMalloc((void**)&part, sizeof(double) * (size_t)per_plane * planes));
+    const double c1 = (0.01 * max_val) * (0.01 * max_val), c2 = (0.03 * max_val) * (0.03 * max_val);
+    if (dtype == DDN_F32)
+        hipLaunchKernelGGL(k_ssim_tile<float>, dim3(per_plane * planes), dim3(256), 0, st, (const float*)x, (const float*)y, H, W, tiles_x, tiles_y, win, c1, c2, part);
+    else
+        hipLaunchKernelGGL(k_ssim_tile<double>, dim3(per_plane * planes), dim3(256), 0, st, (const double*)x, (const double*)y, H, W, tiles_x, tiles_y, win, c1, c2, part);
+    hipLaunchKernelGGL(k_ssim_final, dim3(planes), dim3(256), 0, st, part, per_plane, (double)H * (double)W, out_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(part);
+    return DDN_OK;
+}

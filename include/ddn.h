@@ -126,6 +126,13 @@ int ddn_prox(int kind, int dtype, const void* x_dev, void* y_dev, size_t n, doub
  * out4_dev: [batch][4] doubles = {sum|d|, sqrt(sum d^2), mean d^2, 10 log10(1/mse)}. */
 int ddn_reduce(int dtype, const void* x_dev, const void* y_dev, size_t n_per_image, int batch, double* out4_dev, void* stream);
 
+/* ssim (core/loss.py:39-110): 11 x 11 Gaussian window (sigma 1.5), zero padding, C1 = (0.01 max_val)^2,
+ * C2 = (0.03 max_val)^2, mean of the SSIM map per plane.  x, y: [planes][H][W]; out_dev: [planes] doubles.
+ * g11_host: the 11 normalised float32 window factors exactly as loss.py:75-81 computes them (the caller
+ * evaluates that expression with the framework the reference uses, so the taps agree bit for bit).
+ * Synchronises the stream.  (A [B,C,H,W] input is B*C planes; the caller averages over C.) */
+int ddn_ssim(int dtype, const void* x_dev, const void* y_dev, int H, int W, int planes, double max_val, const float* g11_host, double* out_dev, void* stream);
+
 /* ---- solver loops -------------------------------------------------------------
  * Each *_run advances the iterate arrays in place by up to n_iters iterations of the
  * reference loop body.  Per iteration the device records, per image, the four loss

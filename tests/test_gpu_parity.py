@@ -379,6 +379,37 @@ def test_full_size_4096_square_vs_oracle_and_tile_path(pkg, golden_dir, monkeypa
         assert np.array_equal(g.numpy(), r.numpy())
 
 
+def test_fused_ssim_vs_reference_golden_and_oracle(pkg, golden_dir):
+    """ddn_ssim (one fused device pass) against the value the reference produced (golden) and against
+    the oracle's restatement of loss.py:39-110 on ragged sizes, [C,H,W] / [B,C,H,W] shapes and fp64."""
+    g = _load(golden_dir, "loss.npz")
+    a, b = torch.from_numpy(g["a"]).cuda(), torch.from_numpy(g["b"]).cuda()
+    v = pkg.core.ssim(a, b)
+    np.testing.assert_allclose(v.cpu().numpy().reshape(-1), g["ssim"], rtol=1e-5)  # float32 contract
+    torch.manual_seed(5)
+    for shape, dt in [((37, 91), torch.float32), ((3, 70, 130), torch.float32), ((2, 3, 64, 64), torch.float32), ((129, 200), torch.float64), ((1024, 1024), torch.float32)]:
+        x = torch.rand(shape, dtype=dt)
+        y = (x + 0.1 * torch.randn(shape, dtype=dt)).clamp(0, 1)
+        if x.dim() == 2:
+            want = O.ssim(x, y)
+        else:
+            # the reference's conv2d call raises for more than one channel (one window, groups = C); the
+            # device kernel takes the documented meaning: per-plane SSIM averaged over the channels
+            x4, y4 = (x[None], y[None]) if x.dim() == 3 else (x, y)
+            want = torch.stack([torch.stack([O.ssim(x4[i, c], y4[i, c])[0] for c in range(x4.shape[1])]).mean() for i in range(x4.shape[0])])
+        got = pkg.core.ssim(x.cuda(), y.cuda())
+        assert got.shape == want.shape and got.dtype == want.dtype
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5 if dt == torch.float32 else 1e-11)
+    # default loss of primal_dr_splitting: the per-iteration path with the fused kernel equals the oracle's run
+    k = _load(golden_dir, "kernels.npz")
+    kern = torch.from_numpy(k["gauss9"])
+    torch.manual_seed(0)
+    bimg = O.add_gaussian_noise(O.circular_convolve2d(torch.rand(1, 64, 64), kern), 0.0, 0.05)[0]
+    xo = O.primal_dr_splitting("l1", kern, bimg, niters=8, loss_function=O.ssim)
+    xg = pkg.primal_dr_splitting("l1", kern, bimg.cuda(), niters=8)
+    assert rel(xg.cpu().numpy(), xo.numpy()) < 1e-5
+
+
 def test_batch_equals_loop_of_single_calls(pkg, golden_dir):
     k = _load(golden_dir, "kernels.npz")
     kern = k["gauss9"]

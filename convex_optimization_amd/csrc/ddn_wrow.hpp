@@ -42,6 +42,16 @@ __device__ __forceinline__ size_t opaque(size_t o) {
     return o;
 }
 
+// A uniform global pointer made opaque (kept in the global address space, so accesses through it stay
+// global_load / global_store with a scalar base): blocks the re-association base + (lane offset) that
+// would otherwise be hoisted out of the row loop as one 64-bit vector address per array.
+template <typename Q>
+__device__ __forceinline__ Q* opaque_ptr(Q* p) {
+    auto g = (__attribute__((address_space(1))) Q*)p;
+    asm volatile("" : "+s"(g));
+    return (Q*)g;
+}
+
 // Spectral row addressing: element k = 64 r + lane of a row sits at rowbase + lane_off + r * rstride
 // (tiles are at most 64 columns wide), rowbase and rstride uniform.
 struct SpecAddr {
@@ -131,13 +141,21 @@ __device__ __forceinline__ void advance(AdmmP<float>::Args& a, size_t o) {
     a.u += o; a.w += o; a.y0 += o; a.y1 += o; a.y2 += o; a.z0 += o; a.z1 += o; a.z2 += o; a.b += o;
     if (a.sol) a.sol += o;
 }
+__device__ __forceinline__ void hide(PdrP<float>::Args& a) { a.z1 = opaque_ptr(a.z1); a.z20 = opaque_ptr(a.z20); a.z21 = opaque_ptr(a.z21); a.z22 = opaque_ptr(a.z22); a.b = opaque_ptr(a.b); }
+__device__ __forceinline__ void hide(PddrP<float>::Args& a) { a.p = opaque_ptr(a.p); a.q0 = opaque_ptr(a.q0); a.q1 = opaque_ptr(a.q1); a.q2 = opaque_ptr(a.q2); a.b = opaque_ptr(a.b); }
+__device__ __forceinline__ void hide(AdmmP<float>::Args& a) {
+    a.u = opaque_ptr(a.u); a.w = opaque_ptr(a.w); a.y0 = opaque_ptr(a.y0); a.y1 = opaque_ptr(a.y1); a.y2 = opaque_ptr(a.y2);
+    a.z0 = opaque_ptr(a.z0); a.z1 = opaque_ptr(a.z1); a.z2 = opaque_ptr(a.z2); a.b = opaque_ptr(a.b);
+    if (a.sol) a.sol = opaque_ptr(a.sol);
+}
 // the arguments with every array moved to register r of the row (pixel 64 r + lane is then element `lane`)
 template <class A>
 __device__ __forceinline__ A at_reg(const A& a, int r) {
     A q = a;
-    // the register offset is opaque too: base + offset then stays a scalar sum and the access takes the
-    // scalar-base form (one shared lane-offset register) instead of one 64-bit address pair per array
-    advance(q, opaque((size_t)(64 * r)));
+    // the advanced pointers are opaque: each access then takes the scalar-base form (one shared
+    // lane-offset register) instead of one hoisted 64-bit vector address per array
+    advance(q, (size_t)(64 * r));
+    hide(q);
     return q;
 }
 
@@ -241,8 +259,8 @@ template <int PD, int SL>
 __device__ __forceinline__ void cp_dual(cx<float> (&d)[64], const CpArgs<float>& a, int lane) {
     struct Q { float z, y0, y1, y2, b; } q[PD];
     const unsigned lo = (unsigned)lane;
-#define DDN_CP_LD(r, e) { (e).z = (a.z + 64 * (r))[lo]; (e).y0 = (a.y0 + 64 * (r))[lo]; (e).y1 = (a.y1 + 64 * (r))[lo]; (e).y2 = (a.y2 + 64 * (r))[lo]; (e).b = (a.b + 64 * (r))[lo]; }
-    float zl = (a.z + 64 * 63)[lo];
+#define DDN_CP_LD(r, e) { (e).z = opaque_ptr(a.z + 64 * (r))[lo]; (e).y0 = opaque_ptr(a.y0 + 64 * (r))[lo]; (e).y1 = opaque_ptr(a.y1 + 64 * (r))[lo]; (e).y2 = opaque_ptr(a.y2 + 64 * (r))[lo]; (e).b = opaque_ptr(a.b + 64 * (r))[lo]; }
+    float zl = opaque_ptr(a.z + 64 * 63)[lo];
 #pragma unroll
     for (int g = 0; g < PD; ++g) DDN_CP_LD(g, q[g])
     float rot_prev = from_prev_lane(zl);  // z[-1] of lane 0 = z[4095]
@@ -262,9 +280,9 @@ __device__ __forceinline__ void cp_dual(cx<float> (&d)[64], const CpArgs<float>&
         const float y0n = g0 - a.s * e.b - a.s * pr0;
         float i1, i2;
         iso(udiv(g1, a.s), udiv(g2, a.s), a.isg, i1, i2);                         // cp:75
-        (a.y0 + 64 * r)[lo] = y0n;
-        (a.y1 + 64 * r)[lo] = g1 - a.s * i1;
-        (a.y2 + 64 * r)[lo] = g2 - a.s * i2;
+        opaque_ptr(a.y0 + 64 * r)[lo] = y0n;
+        opaque_ptr(a.y1 + 64 * r)[lo] = g1 - a.s * i1;
+        opaque_ptr(a.y2 + 64 * r)[lo] = g2 - a.s * i2;
         slot<SL>(d[r]) = y0n;
         asm volatile("" : "+v"(slot<SL>(d[r])));
     }
@@ -276,7 +294,7 @@ template <int PD, int SL>
 __device__ __forceinline__ void cp_primal(cx<float> (&d)[64], const CpArgs<float>& a, int lane, double (&acc)[4]) {
     struct Q { float x, b, y1, y2; } q[PD];
     const unsigned lo = (unsigned)lane;
-#define DDN_CP_LD(r, e) { (e).x = (a.x + 64 * (r))[lo]; (e).b = (a.b + 64 * (r))[lo]; (e).y1 = (a.y1 + 64 * (r))[lo]; (e).y2 = (a.y2 + 64 * (r))[lo]; }
+#define DDN_CP_LD(r, e) { (e).x = opaque_ptr(a.x + 64 * (r))[lo]; (e).b = opaque_ptr(a.b + 64 * (r))[lo]; (e).y1 = opaque_ptr(a.y1 + 64 * (r))[lo]; (e).y2 = opaque_ptr(a.y2 + 64 * (r))[lo]; }
 #pragma unroll
     for (int g = 0; g < PD; ++g) DDN_CP_LD(g, q[g])
     // D^T(y1 + y2)[j] = s[j] - s[j+1]: register r is finished when s of register r+1 is known
@@ -287,8 +305,8 @@ __device__ __forceinline__ void cp_primal(cx<float> (&d)[64], const CpArgs<float
         const float zn = 2.f * xn - x_prev;                                       /* cp:87 */  \
         const float dd = xn - b_prev;                                             /* cp:96 */  \
         acc[0] += (double)t_abs(dd); acc[1] += (double)dd * (double)dd;                         \
-        (a.x + 64 * (r))[lo] = xn;                                                              \
-        (a.z + 64 * (r))[lo] = zn;                                                              \
+        opaque_ptr(a.x + 64 * (r))[lo] = xn;                                                    \
+        opaque_ptr(a.z + 64 * (r))[lo] = zn;                                                    \
         slot<SL>(d[r]) = zn;                                                                    \
         asm volatile("" : "+v"(slot<SL>(d[r]))); }
 #pragma unroll
@@ -312,7 +330,7 @@ __device__ __forceinline__ void cp_primal(cx<float> (&d)[64], const CpArgs<float
 template <int SL>
 __device__ __forceinline__ void cp_load_z(cx<float> (&d)[64], const CpArgs<float>& a, int lane) {
 #pragma unroll
-    for (int r = 0; r < 64; ++r) slot<SL>(d[r]) = (a.z + 64 * r)[(unsigned)lane];
+    for (int r = 0; r < 64; ++r) slot<SL>(d[r]) = opaque_ptr(a.z + 64 * r)[(unsigned)lane];
 }
 
 __device__ __forceinline__ void advance(CpArgs<float>& a, size_t o) { a.x += o; a.z += o; a.y0 += o; a.y1 += o; a.y2 += o; a.b += o; }

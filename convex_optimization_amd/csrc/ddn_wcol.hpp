@@ -254,6 +254,12 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
     if (dense) {
 #pragma unroll
         for (int r = 0; r < 64; ++r) d[r] = mk<float>(wq == 0 ? dcol[64 * r + lane] : 0.f, 0.f);
+    } else if ((cs == 2 && !(a.dbg_mode & 16)) || (cs != 2 && (a.dbg_mode & 64))) {
+        // 4-column tiles: the quarter is one contiguous block of rows x 4 columns; each wave reads its
+        // own column directly (32-byte stride; the four waves of a half use every byte of every line)
+        const cx<float>* const colp = Sarr + qbase + wq;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) d[r] = (colp + ((size_t)(64 * r) << cs))[(unsigned)lane << cs];
     } else load_quarter(d, Sarr + qbase, C, stg, wq, lane, true, a.dbg_mode);
     if (packed) {
         const unsigned noff = (unsigned)(lane << cs);
@@ -329,6 +335,12 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
         if (wq == 0) {
 #pragma unroll
             for (int r = 0; r < 64; ++r) dcol[64 * r + lane] = d[r].x;
+        }
+    } else if (cs == 2 && (a.dbg_mode & 32)) {  // direct stores measured slower than the staged ones: diagnostic only
+        if (wq < ncols) {
+            cx<float>* const colp = Sarr + opaque(qbase) + wq;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) (colp + (size_t)(64 * r) * 4)[(unsigned)lane * 4u] = d[r];
         }
     } else store_quarter(d, Sarr + opaque(qbase), C, stg, wq, lane, true, ncols);
     if (packed) {

@@ -301,4 +301,81 @@ __device__ __forceinline__ void fft4096(cx<float> (&d)[64], const cx<float>* twt
 }
 #endif
 
+
+// ---- shorter sequences: N = 64 R, R in {8, 16, 32}, M = 64 / R sequences per wavefront ------------------
+// Pixel-side layout ("A"): register q R + j of lane l holds element 64 j + l of sequence q -- for rows
+// stored back to back that is element 64 (register) + lane of one contiguous 4096-element segment,
+// exactly the layout of the 4096-point case.  Frequency-side layout ("B"): lane q R + k1, register k2
+// holds frequency k1 + R k2 of sequence q (R consecutive frequencies of a sequence per register).
+// forward: A -> B  (R-point transforms in registers, twiddle w_N^(lane k1), the 64 x 64 transposition,
+//                   64-point transforms);   inverse: B -> A, the same steps backwards.
+// Per-lane twiddles: table [lane][R] = w_N^(lane k1), forward sign.
+template <int R, bool INV>
+__device__ __forceinline__ void small_dft(cx<float>* v) {
+    if constexpr (R == 32) {
+        cx<float> e[16], o[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            e[i] = v[2 * i];
+            o[i] = v[2 * i + 1];
+        }
+        Dft<float, 16, INV>::run(e);
+        Dft<float, 16, INV>::run(o);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            // w32^k = w64^(2k)
+            const cx<float> w = mk<float>((float)cos64(2 * k), (float)(INV ? sin64(2 * k) : -sin64(2 * k)));
+            const cx<float> t = (k == 0) ? o[0] : o[k] * w;
+            v[k] = e[k] + t;
+            v[k + 16] = e[k] - t;
+        }
+    } else {
+        Dft<float, R, INV>::run(v);
+    }
+}
+
+template <int R, bool INV>
+__device__ __forceinline__ void fftN(cx<float> (&d)[64], const cx<float>* twtab, float* tile, int lane) {
+    constexpr int M = 64 / R;
+    cx<float> tw[R];
+    {
+        unsigned off = (unsigned)lane * (unsigned)R;
+        asm volatile("" : "+v"(off));
+        const cx<float>* t = twtab + off;
+#pragma unroll
+        for (int i = 0; i < R; ++i) tw[i] = t[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!INV) {
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+            cx<float> v[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[j] = d[q * R + j];
+            small_dft<R, false>(v);
+#pragma unroll
+            for (int k = 0; k < R; ++k) d[q * R + k] = (k == 0) ? v[0] : v[k] * tw[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        transpose64(d, tile, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        fft64<false>(d);
+    } else {
+        fft64<true>(d);
+        __builtin_amdgcn_sched_barrier(0);
+        transpose64(d, tile, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+            cx<float> v[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) v[k] = (k == 0) ? d[q * R] : mulc(d[q * R + k], tw[k]);
+            small_dft<R, true>(v);
+#pragma unroll
+            for (int j = 0; j < R; ++j) d[q * R + j] = v[j];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 }  // namespace wfft

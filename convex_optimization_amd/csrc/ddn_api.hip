@@ -152,6 +152,7 @@ struct ddn_plan {
     // device buffers (typed by dtype)
     void* twW = nullptr;
     void* wtw = nullptr;     // per-lane twiddles of the register-resident 4096-point transform (float) or null
+    void* wtwW = nullptr;    // per-lane twiddles w_W^(lane k), k < W / 64, of the W = 512 / 1024 / 2048 row transforms, or null
     void* nyqd = nullptr;    // dense home of spectral column W/2 while a solver loop runs on the wave kernels
     bool nyqd_on = false;
     void* eKc = nullptr;     // column-major natural-order copies of eK and G for the wave-per-column stage
@@ -303,6 +304,15 @@ int plan_alloc(ddn_plan* p) {
             }
         HIPCHK(hipMalloc(&p->wtw, tab.size() * sizeof(cx<float>)));
         HIPCHK(hipMemcpy(p->wtw, tab.data(), tab.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
+    }
+    if (sizeof(T) == 4 && (p->W == 512 || p->W == 1024 || p->W == 2048)) {
+        const int R = p->W / 64;
+        std::vector<cx<float>> tab(64 * R);
+        const long double tp = -2.0L * 3.14159265358979323846264338327950288L / (long double)p->W;
+        for (int l = 0; l < 64; ++l)
+            for (int k = 0; k < R; ++k) tab[l * R + k] = {(float)cosl(tp * (l * k)), (float)sinl(tp * (l * k))};
+        HIPCHK(hipMalloc(&p->wtwW, tab.size() * sizeof(cx<float>)));
+        HIPCHK(hipMemcpy(p->wtwW, tab.data(), tab.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
     }
     if ((rc = alloc_col_tables<T>(p))) return rc;
     if ((rc = alloc_spec<T>(p))) return rc;
@@ -490,8 +500,14 @@ struct RowCfg {
 // Row workgroup shape: V = 4 pixels per lane-access (16 B) and four groups per thread when the
 // arrays are 16-byte aligned and W <= 4096; otherwise scalar accesses, eight pixels per thread.
 template <typename T>
-bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc) {
+bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool cp = false) {
     const int W = p->W;
+    if (sizeof(T) == 4 && p->wtwW && !cp && !p->injected && p->H % (4096 / W) == 0 && !getenv("DDN_NO_WAVE_ROWS")) {
+        // one wavefront per 4096 / W consecutive rows (ddn_wrown.hpp)
+        rc.V = 0; rc.threads = 64; rc.lds = 0;
+        rc.grid = std::max(1, std::min(work_items / (4096 / W), p->num_cu * 8));
+        return true;
+    }
     if (sizeof(T) == 4 && p->wtw && W == 4096 && !p->injected && !getenv("DDN_NO_WAVE_ROWS")) {
         // one wavefront per row, eight per CU (256 registers each), the row held in registers
         // (four rows per workgroup with 4-column spectral tiles, see ddn_wrow.hpp)
@@ -526,7 +542,7 @@ RowCommon<T> row_common(ddn_plan* p, int V, bool consume, bool produce) {
     std::memset(&c, 0, sizeof(c));
     c.H = p->H; c.W = p->W; c.batch = p->batch;
     c.V_groups = V ? p->W / V : 0;
-    c.wtw = (const cx<T>*)p->wtw;
+    c.wtw = (const cx<T>*)(p->W == 4096 ? p->wtw : p->wtwW);
     c.nyqd = p->nyqd_on ? (T*)p->nyqd : nullptr;
     c.fw = p->fw;
     c.lay = layout_of(p);
@@ -721,7 +737,7 @@ struct NyqDense {
     ddn_plan* p;
     NyqDense(ddn_plan* p_, bool wave_rows) : p(p_) {
         p->nyqd_on = false;
-        if (!wave_rows || !wcol_ready(p) || p->W % 2 || (p->Wh & 3) != 1 || getenv("DDN_NO_NYQ_DENSE")) return;
+        if (!wave_rows || p->W != 4096 || !wcol_ready(p) || p->W % 2 || (p->Wh & 3) != 1 || getenv("DDN_NO_NYQ_DENSE")) return;
         if (!p->nyqd && hipMalloc(&p->nyqd, sizeof(float) * 2 * (size_t)p->batch * p->H) != hipSuccess) { p->nyqd = nullptr; return; }
         p->nyqd_on = true;
     }
@@ -843,7 +859,7 @@ int cp_run_impl(ddn_plan* p, void* x, void* z, void* y, const void* b, double t,
     const size_t plane = (size_t)p->batch * p->H * p->W;
     RowCfg cfg;
     const bool al = aligned16(x) && aligned16(z) && aligned16(y) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
-    if (!row_cfg<T>(p, al, p->batch * ((p->H + 1) / 2), cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    if (!row_cfg<T>(p, al, p->batch * ((p->H + 1) / 2), cfg, true)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
     NyqDense nyq_guard(p, cfg.V == 0);
     CpArgs<T> a;
     RowCommon<T> rc0;
@@ -957,7 +973,7 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
 
 int ddn_plan_destroy(ddn_plan* p) {
     if (!p) return DDN_OK;
-    void* bufs[] = {p->twW, p->wtw, p->nyqd, p->eKc, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
+    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->nyqd, p->eKc, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : p->ev_pool) {

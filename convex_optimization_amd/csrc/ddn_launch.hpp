@@ -63,6 +63,9 @@ int row_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCom
 template <class P>
 int wrow_launch(hipStream_t st, int grid, const RowCommon<float>& c, const typename P::Args& a);
 int wrow_cp_launch(hipStream_t st, int grid, const RowCommon<float>& c, const CpArgs<float>& a);
+// The same for W = 512, 1024, 2048 (several rows per wavefront; ddn_wrown.hpp), in ddn_wrown_*.hip.
+template <class P>
+int wrown_launch(hipStream_t st, int grid, const RowCommon<float>& c, const typename P::Args& a);
 // Wave-per-column single-pass column stage (H = 4096, float; ddn_wcol.hpp), in ddn_wcol.hip.
 int wcol_launch(hipStream_t st, int mode, const wcol::Args& a);
 
@@ -70,7 +73,7 @@ template <typename T, class P>
 int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const RowCommon<T>& c, const typename P::Args& a) {
     const bool spec = c.eDrow != nullptr;
     if constexpr (sizeof(T) == 4) {
-        if (V == 0) return wrow_launch<P>(st, grid, c, a);
+        if (V == 0) return c.W == 4096 ? wrow_launch<P>(st, grid, c, a) : wrown_launch<P>(st, grid, c, a);
     }
     if (V == 4) {
         if (spec) return launch_row_fn(st, k_solver_row<T, P, 4, 4, true, 0, 0, 256, 2>, grid, threads, lds, c, a);

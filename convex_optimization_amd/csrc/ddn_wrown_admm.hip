@@ -1,0 +1,10 @@
+// Wave-per-row-group admm kernels for W = 512, 1024, 2048 (float): 64 / (W / 64) rows per wavefront
+// (ddn_wrown.hpp); full iteration, consume-only and produce-only variants.
+#define DDN_WAVE_FAST 1
+#include "ddn_launch.hpp"
+#include "ddn_wrown.hpp"
+
+template <>
+int wrown_launch<AdmmP<float>>(hipStream_t st, int grid, const RowCommon<float>& c, const AdmmP<float>::Args& a) {
+    return wrow::wrown_dispatch<AdmmP<float>, 2, 1>(st, grid, c, a);
+}

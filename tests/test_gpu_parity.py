@@ -300,6 +300,40 @@ def test_width_4096_wave_rows_vs_oracle(pkg, golden_dir, H):
         assert np.array_equal(xb[i].numpy(), xi.numpy())
 
 
+@pytest.mark.parametrize("W,H", [(512, 24), (1024, 16), (1024, 20), (2048, 18)])
+def test_widths_512_1024_2048_wave_row_groups_vs_oracle(pkg, golden_dir, W, H):
+    """W = 512 / 1024 / 2048 float32 with H a multiple of 4096 / W takes the kernels that hold
+    4096 / W consecutive rows in one wavefront's registers (primal_dr, primal_dual_dr, admm): against
+    the CPU oracle at N = 20, both objectives, recorded losses included; a batch of two equals two
+    single calls bit for bit (a wavefront's rows never straddle two images)."""
+    k = _load(golden_dir, "kernels.npz")
+    kern = torch.from_numpy(k["motion15_45"])
+    torch.manual_seed(0)
+    img = torch.rand(1, H, W)
+    b = O.add_gaussian_noise(O.circular_convolve2d(img, kern), 0.0, 0.05)[0]
+    N = 20
+    torch.manual_seed(7)
+    for obj in ("l1", "l2"):
+        stA = tuple(torch.clamp(torch.randn(s, dtype=torch.float32), 0, 1) for s in [(H, W), (H, W), (3, H, W), (3, H, W)])
+        lo, lg = [], []
+        xo = O.admm_solver(b, obj, kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, loss_function=O.psnr, losses=lo)
+        x, lg = pkg.admm_solver(b, obj, kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, return_losses=True)
+        assert rel(x.numpy(), xo.numpy()) < 1e-5
+        assert np.allclose(np.asarray(lg, dtype=np.float64), np.asarray(lo, dtype=np.float64), rtol=2e-5)
+        xo = O.primal_dr_splitting(obj, kern, b, niters=N)
+        x = pkg.primal_dr_splitting(obj, kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0)
+        assert rel(x.numpy(), xo.numpy()) < 1e-5
+    stP = (torch.rand(H, W), torch.rand(3, H, W))
+    xo = O.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP)
+    x = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP, tol=-1.0)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    b2 = torch.stack((b, b.flip(0)))
+    xb = pkg.primal_dr_splitting("l1", kern, b2, niters=5, loss_function=pkg.core.mse, tol=-1.0)
+    for i in range(2):
+        xi = pkg.primal_dr_splitting("l1", kern, b2[i], niters=5, loss_function=pkg.core.mse, tol=-1.0)
+        assert np.array_equal(xb[i].numpy(), xi.numpy())
+
+
 def test_height_4096_wave_columns_vs_oracle(pkg, golden_dir):
     """H = 4096 float32 takes the single-pass one-wavefront-per-column stage (both the resolvent and
     the plain multiplier form): all four solvers against the CPU oracle at 4096 x 32, N = 10, and

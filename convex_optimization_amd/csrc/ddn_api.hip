@@ -502,10 +502,11 @@ struct RowCfg {
 template <typename T>
 bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool cp = false) {
     const int W = p->W;
-    if (sizeof(T) == 4 && p->wtwW && !cp && !p->injected && p->H % (4096 / W) == 0 && !getenv("DDN_NO_WAVE_ROWS")) {
-        // one wavefront per 4096 / W consecutive rows (ddn_wrown.hpp)
+    if (sizeof(T) == 4 && p->wtwW && !p->injected && p->H % ((cp ? 2 : 1) * (4096 / W)) == 0 && !getenv("DDN_NO_WAVE_ROWS")) {
+        // one wavefront per 4096 / W consecutive rows, twice as many for Chambolle-Pock (ddn_wrown.hpp)
         rc.V = 0; rc.threads = 64; rc.lds = 0;
-        rc.grid = std::max(1, std::min(work_items / (4096 / W), p->num_cu * 8));
+        const int items = p->batch * p->H / ((cp ? 2 : 1) * (4096 / W));
+        rc.grid = std::max(1, std::min(items, p->num_cu * 8));
         return true;
     }
     if (sizeof(T) == 4 && p->wtw && W == 4096 && !p->injected && !getenv("DDN_NO_WAVE_ROWS")) {

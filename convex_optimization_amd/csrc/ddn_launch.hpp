@@ -66,6 +66,7 @@ int wrow_cp_launch(hipStream_t st, int grid, const RowCommon<float>& c, const Cp
 // The same for W = 512, 1024, 2048 (several rows per wavefront; ddn_wrown.hpp), in ddn_wrown_*.hip.
 template <class P>
 int wrown_launch(hipStream_t st, int grid, const RowCommon<float>& c, const typename P::Args& a);
+int wrown_cp_launch(hipStream_t st, int grid, const RowCommon<float>& c, const CpArgs<float>& a);
 // Wave-per-column single-pass column stage (H = 4096, float; ddn_wcol.hpp), in ddn_wcol.hip.
 int wcol_launch(hipStream_t st, int mode, const wcol::Args& a);
 
@@ -101,7 +102,7 @@ template <typename T>
 int cp_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const RowCommon<T>& c, const CpArgs<T>& a) {
     const bool spec = c.eDrow != nullptr;
     if constexpr (sizeof(T) == 4) {
-        if (V == 0) return wrow_cp_launch(st, grid, c, a);
+        if (V == 0) return c.W == 4096 ? wrow_cp_launch(st, grid, c, a) : wrown_cp_launch(st, grid, c, a);
     }
     if (V == 4) {
         if (spec) return launch_row_fn(st, k_cp_row<T, 4, 4, true, 0, 256, 2>, grid, threads, lds, c, a);

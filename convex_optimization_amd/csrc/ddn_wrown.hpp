@@ -197,4 +197,153 @@ int wrown_dispatch(hipStream_t st, int grid, const RowCommon<float>& c, const ty
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Chambolle-Pock (chambolle_pock/algorithm.py:58-92; see k_wave_cp): a wave owns 2 M consecutive
+// image rows, the first M in the real slot and the next M in the imaginary slot of the M complex
+// transforms.  H is a multiple of 2 M.
+template <int PD, int SL, int R>
+__device__ __forceinline__ void cp_dualN(cx<float> (&d)[64], const CpArgs<float>& a, int lane) {
+    struct Q { float z, y0, y1, y2, b; } q[PD];
+    const unsigned lo = (unsigned)lane;
+#define DDN_CP_LD(r, e) { (e).z = opaque_ptr(a.z + 64 * (r))[lo]; (e).y0 = opaque_ptr(a.y0 + 64 * (r))[lo]; (e).y1 = opaque_ptr(a.y1 + 64 * (r))[lo]; (e).y2 = opaque_ptr(a.y2 + 64 * (r))[lo]; (e).b = opaque_ptr(a.b + 64 * (r))[lo]; }
+    float zl = opaque_ptr(a.z + 64 * (R - 1))[lo];  // last register of the row: z[-1] of lane 0
+#pragma unroll
+    for (int g = 0; g < PD; ++g) DDN_CP_LD(g, q[g])
+    float rot_prev = 0.f;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+        const int j = r % R;
+        sched_fence();
+        if (j == 0) {
+            rot_prev = from_prev_lane(zl);
+            if (r + R < 64) zl = opaque_ptr(a.z + 64 * (r + 2 * R - 1))[lo];  // for the next row, a row ahead
+        }
+        const Q e = q[r % PD];
+        if (r + PD < 64) DDN_CP_LD(r + PD, q[r % PD])
+        const float in = slot<SL>(d[r]);
+        const float rot = from_prev_lane(e.z);
+        const float dz = e.z - (lane == 0 ? rot_prev : rot);                      // cp:61
+        rot_prev = rot;
+        const float g0 = e.y0 + a.s * in;                                         // cp:66
+        const float g1 = e.y1 + a.s * dz;
+        const float g2 = e.y2 + a.s * dz;
+        const float pr0 = data_prox(a.objective, udiv(g0, a.s) - e.b, a.is, a.l2div);   // cp:69-72
+        const float y0n = g0 - a.s * e.b - a.s * pr0;
+        float i1, i2;
+        iso(udiv(g1, a.s), udiv(g2, a.s), a.isg, i1, i2);                         // cp:75
+        opaque_ptr(a.y0 + 64 * r)[lo] = y0n;
+        opaque_ptr(a.y1 + 64 * r)[lo] = g1 - a.s * i1;
+        opaque_ptr(a.y2 + 64 * r)[lo] = g2 - a.s * i2;
+        slot<SL>(d[r]) = y0n;
+        asm volatile("" : "+v"(slot<SL>(d[r])));
+    }
+#undef DDN_CP_LD
+    sched_fence();
+}
+
+// partials: the loss partials of the slot's first row (four doubles per row)
+template <int PD, int SL, int R>
+__device__ __forceinline__ void cp_primalN(cx<float> (&d)[64], const CpArgs<float>& a, int lane, double* partials) {
+    struct Q { float x, b, y1, y2; } q[PD];
+    const unsigned lo = (unsigned)lane;
+#define DDN_CP_LD(r, e) { (e).x = opaque_ptr(a.x + 64 * (r))[lo]; (e).b = opaque_ptr(a.b + 64 * (r))[lo]; (e).y1 = opaque_ptr(a.y1 + 64 * (r))[lo]; (e).y2 = opaque_ptr(a.y2 + 64 * (r))[lo]; }
+#pragma unroll
+    for (int g = 0; g < PD; ++g) DDN_CP_LD(g, q[g])
+    double acc[4] = {0, 0, 0, 0};
+    // D^T(y1 + y2)[p] = s[p] - s[p+1]: register r is finished when s of the row's next register is known
+    float rs_first = 0.f, rs_prev = 0.f, in_prev = 0.f, sc_prev = 0.f, x_prev = 0.f, b_prev = 0.f;
+#define DDN_CP_FIN(r, snext) {                                                                 \
+        const float aty = in_prev + (sc_prev - (snext));                          /* cp:79 */  \
+        const float xn = clip01(x_prev - a.t * aty);                              /* cp:83-86 */ \
+        const float zn = 2.f * xn - x_prev;                                       /* cp:87 */  \
+        const float dd = xn - b_prev;                                             /* cp:96 */  \
+        acc[0] += (double)t_abs(dd); acc[1] += (double)dd * (double)dd;                         \
+        opaque_ptr(a.x + 64 * (r))[lo] = xn;                                                    \
+        opaque_ptr(a.z + 64 * (r))[lo] = zn;                                                    \
+        slot<SL>(d[r]) = zn;                                                                    \
+        asm volatile("" : "+v"(slot<SL>(d[r]))); }
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+        const int j = r % R;
+        sched_fence();
+        const Q e = q[r % PD];
+        if (r + PD < 64) DDN_CP_LD(r + PD, q[r % PD])
+        const float in = slot<SL>(d[r]);
+        const float sc = e.y1 + e.y2;
+        const float rs = from_next_lane(sc);
+        if (j == 0) rs_first = rs;
+        else DDN_CP_FIN(r - 1, lane == 63 ? rs : rs_prev)
+        rs_prev = rs; in_prev = in; sc_prev = sc; x_prev = e.x; b_prev = e.b;
+        if (j == R - 1) {
+            DDN_CP_FIN(r, lane == 63 ? rs_first : rs)
+            wave_sum<4>(acc);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) partials[(size_t)(r / R) * 4 + i] = acc[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = 0.0;
+        }
+    }
+#undef DDN_CP_FIN
+#undef DDN_CP_LD
+    sched_fence();
+}
+
+template <int PD, int STEP, bool CONS, bool PROD, int R>
+__global__ void __launch_bounds__(64, 2) k_wave_cpN(RowCommon<float> c, CpArgs<float> a0) {
+    constexpr int M = 64 / R;
+    extern __shared__ __align__(16) float wtiles[];
+    const int lane = threadIdx.x & 63, H = c.H;
+    float* const tile = wtiles;
+    const int nitems = c.batch * H / (2 * M);
+    const SpecAddrN<R> sa(c.lay, lane);
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int row = it * 2 * M;
+        const int plane = row / H;
+        const int r0 = row - plane * H;
+        CpArgs<float> a = a0, a1 = a0;
+        advance(a, opaque((size_t)it * 8192));
+        advance(a1, opaque((size_t)it * 8192 + 4096));
+        cx<float>* const rw0 = c.S0 + opaque(spec_row_base(c.lay, plane, r0));
+        cx<float>* const rw1 = c.S0 + opaque(spec_row_base(c.lay, plane, r0 + M));
+        cx<float> d[64];
+        if (CONS) {
+            packN<R>(d, rw0, rw1, sa, lane);
+            wfft::fftN<R, true>(d, c.wtw, tile, lane);
+            pin(d);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 64; ++r) d[r] = mk<float>(0.f, 0.f);
+        }
+        sched_fence();
+        if (STEP == 0) {
+            cp_dualN<PD, 0, R>(d, a, lane);
+            cp_dualN<PD, 1, R>(d, a1, lane);
+        } else if (CONS) {
+            cp_primalN<PD, 0, R>(d, a, lane, c.partials + (size_t)row * 4);
+            cp_primalN<PD, 1, R>(d, a1, lane, c.partials + (size_t)(row + M) * 4);
+        } else {
+            cp_load_z<0>(d, a, lane);
+            cp_load_z<1>(d, a1, lane);
+        }
+        if (PROD) {
+            pin(d);
+            sched_fence();
+            wfft::fftN<R, false>(d, c.wtw, tile, lane);
+            pin(d);
+            unpackN<R>(d, rw0, rw1, sa, lane);
+        }
+    }
+}
+
+template <int PD, int R>
+int wrown_cp_go(hipStream_t st, int grid, const RowCommon<float>& c, const CpArgs<float>& a) {
+    const size_t lds = (size_t)WFFT_TILE_FLOATS * sizeof(float);
+    if (a.step == 0) return launch_row_fn(st, k_wave_cpN<PD, 0, true, true, R>, grid, 64, lds, c, a);
+    if (!c.do_consume) return launch_row_fn(st, k_wave_cpN<PD, 1, false, true, R>, grid, 64, lds, c, a);
+    if (c.do_produce) return launch_row_fn(st, k_wave_cpN<PD, 1, true, true, R>, grid, 64, lds, c, a);
+    return launch_row_fn(st, k_wave_cpN<PD, 1, true, false, R>, grid, 64, lds, c, a);
+}
+
 }  // namespace wrow

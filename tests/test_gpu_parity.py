@@ -300,12 +300,13 @@ def test_width_4096_wave_rows_vs_oracle(pkg, golden_dir, H):
         assert np.array_equal(xb[i].numpy(), xi.numpy())
 
 
-@pytest.mark.parametrize("W,H", [(512, 24), (1024, 16), (1024, 20), (2048, 18)])
+@pytest.mark.parametrize("W,H", [(512, 24), (512, 32), (1024, 16), (1024, 20), (2048, 18), (2048, 20)])
 def test_widths_512_1024_2048_wave_row_groups_vs_oracle(pkg, golden_dir, W, H):
     """W = 512 / 1024 / 2048 float32 with H a multiple of 4096 / W takes the kernels that hold
-    4096 / W consecutive rows in one wavefront's registers (primal_dr, primal_dual_dr, admm): against
-    the CPU oracle at N = 20, both objectives, recorded losses included; a batch of two equals two
-    single calls bit for bit (a wavefront's rows never straddle two images)."""
+    4096 / W consecutive rows in one wavefront's registers (Chambolle-Pock: twice as many, and H a
+    multiple of that; the heights 24, 20 and 18 leave it on the workgroup-per-row kernels): all four
+    solvers against the CPU oracle at N = 20, both objectives, recorded losses included; a batch of
+    two equals two single calls bit for bit (a wavefront's rows never straddle two images)."""
     k = _load(golden_dir, "kernels.npz")
     kern = torch.from_numpy(k["motion15_45"])
     torch.manual_seed(0)
@@ -313,7 +314,11 @@ def test_widths_512_1024_2048_wave_row_groups_vs_oracle(pkg, golden_dir, W, H):
     b = O.add_gaussian_noise(O.circular_convolve2d(img, kern), 0.0, 0.05)[0]
     N = 20
     torch.manual_seed(7)
+    st = (torch.rand(H, W), torch.rand(H, W), torch.rand(3, H, W))
     for obj in ("l1", "l2"):
+        xo = O.chambolle_pock(b[None], kern, objective_function=obj, max_iter=N + 1, init_state=st)
+        x = pkg.chambolle_pock_solver(b[None], kern, objective_function=obj, max_iter=N + 1, init_state=st)
+        assert rel(x.numpy(), xo.numpy()) < 1e-5
         stA = tuple(torch.clamp(torch.randn(s, dtype=torch.float32), 0, 1) for s in [(H, W), (H, W), (3, H, W), (3, H, W)])
         lo, lg = [], []
         xo = O.admm_solver(b, obj, kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, loss_function=O.psnr, losses=lo)
@@ -328,6 +333,12 @@ def test_widths_512_1024_2048_wave_row_groups_vs_oracle(pkg, golden_dir, W, H):
     x = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP, tol=-1.0)
     assert rel(x.numpy(), xo.numpy()) < 1e-5
     b2 = torch.stack((b, b.flip(0)))
+    sts = [st, tuple(t.flip(-1) for t in st)]
+    st2 = (torch.stack((sts[0][0], sts[1][0])), torch.stack((sts[0][1], sts[1][1])), torch.stack((sts[0][2], sts[1][2]), dim=1))
+    xb = pkg.chambolle_pock_solver(b2, kern, max_iter=6, init_state=st2)
+    for i in range(2):
+        xi = pkg.chambolle_pock_solver(b2[i][None], kern, max_iter=6, init_state=sts[i])
+        assert np.array_equal(xb[i].numpy(), xi[0].numpy())
     xb = pkg.primal_dr_splitting("l1", kern, b2, niters=5, loss_function=pkg.core.mse, tol=-1.0)
     for i in range(2):
         xi = pkg.primal_dr_splitting("l1", kern, b2[i], niters=5, loss_function=pkg.core.mse, tol=-1.0)

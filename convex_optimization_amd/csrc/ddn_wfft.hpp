@@ -127,8 +127,13 @@ __device__ __forceinline__ void wave_sync() {
 // Transposition through the wave's LDS tile: on entry lane l holds d[k] = T(k, l); on exit lane l
 // holds d[n] = T(l, n).
 __device__ __forceinline__ void transpose64(cx<float> (&d)[64], float* tile, int lane) {
-    float* wr = tile + lane;
-    const float* rd = tile + lane * 65;
+    // the lane's tile addresses are rebuilt here on every call (opaque lane index): as loop invariants
+    // they would be hoisted out of the row loop, sixteen registers (one per 1 KB of paired-write
+    // offset range) held through the per-pixel phase that has none to spare
+    unsigned lo = (unsigned)lane;
+    asm volatile("" : "+v"(lo));
+    float* wr = tile + lo;
+    const float* rd = tile + lo * 65u;
 #pragma unroll
     for (int k = 0; k < 64; ++k) wr[k * 65] = d[k].x;
     wave_sync();

@@ -162,7 +162,7 @@ __device__ __forceinline__ A at_reg(const A& a, int r) {
 // ----------------------------------------------------------------------------------------------
 // PDR / PDDR / ADMM: the policies of ddn_kernels.hpp, one pixel per register.
 // PD = depth of the iterate-array load pipeline (registers r .. r+PD-1 are in flight).
-template <class P, int PD, bool CONS, bool PROD, int FE = 1, int WPW = 1>
+template <class P, int PD, bool CONS, bool PROD, int FE = 1, int WPW = 1, int SP = 0>
 #ifndef WROW_MINW
 #define WROW_MINW 2
 #endif
@@ -216,6 +216,10 @@ __global__ void __launch_bounds__(64 * WPW, WROW_MINW) k_wave_row(RowCommon<floa
             rot_prev = rot;
             P::template step_regs<1>(at_reg(a, r), CONS, PROD, ul, stq[r % PD], u, k, du, re, im, s, acc);
             if (r + PD < 64) P::template load<1>(at_reg(a, r + PD), ul, stq[r % PD]);
+            // SP > 0: a never-taken use of an accumulator every SP registers.  Measured, not derived:
+            // with it the register allocator keeps admm's whole row in registers (without: 67
+            // registers per lane spilled, 9 % more memory traffic); pdr / pddr fit without and spill with.
+            if (SP > 0 && CONS && r % (SP > 0 ? SP : 1) == (SP > 0 ? SP : 1) - 1 && r != 63 && c.batch < 0) c.partials[0] = acc[0];
             if (PROD) {
                 // transform input: re + D^T s = re + s[j] - s[j+1]; s[j+1] sits in lane l+1, or for lane 63 in lane 0 of the next register
                 const float rs = from_next_lane(s[0]);
@@ -290,8 +294,10 @@ __device__ __forceinline__ void cp_dual(cx<float> (&d)[64], const CpArgs<float>&
     sched_fence();
 }
 
+// partials: the row's four loss partials (summed over the wave here, written by lane 0)
 template <int PD, int SL>
-__device__ __forceinline__ void cp_primal(cx<float> (&d)[64], const CpArgs<float>& a, int lane, double (&acc)[4]) {
+__device__ __forceinline__ void cp_primal(cx<float> (&d)[64], const CpArgs<float>& a, int lane, double* partials) {
+    double acc[4] = {0, 0, 0, 0};
     struct Q { float x, b, y1, y2; } q[PD];
     const unsigned lo = (unsigned)lane;
 #define DDN_CP_LD(r, e) { (e).x = opaque_ptr(a.x + 64 * (r))[lo]; (e).b = opaque_ptr(a.b + 64 * (r))[lo]; (e).y1 = opaque_ptr(a.y1 + 64 * (r))[lo]; (e).y2 = opaque_ptr(a.y2 + 64 * (r))[lo]; }
@@ -325,6 +331,13 @@ __device__ __forceinline__ void cp_primal(cx<float> (&d)[64], const CpArgs<float
 #undef DDN_CP_FIN
 #undef DDN_CP_LD
     sched_fence();
+    // reduced and stored here, per slot: accumulators kept live across the other slot's pass
+    // (and one reduction for both) cost 70 spilled registers per lane
+    wave_sum<4>(acc);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) partials[q] = acc[q];
+    }
 }
 
 template <int SL>
@@ -373,13 +386,12 @@ __global__ void __launch_bounds__(64 * WPW, 2) k_wave_cp(RowCommon<float> c, CpA
             for (int r = 0; r < 64; ++r) d[r] = mk<float>(0.f, 0.f);
         }
         sched_fence();
-        double acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
         if (STEP == 0) {
             cp_dual<PD, 0>(d, a, lane);
             if (two) cp_dual<PD, 1>(d, a1, lane);
         } else if (CONS) {
-            cp_primal<PD, 0>(d, a, lane, acc0);
-            if (two) cp_primal<PD, 1>(d, a1, lane, acc1);
+            cp_primal<PD, 0>(d, a, lane, c.partials + row0 * 4);
+            if (two) cp_primal<PD, 1>(d, a1, lane, c.partials + (row0 + 1) * 4);
         } else {
             cp_load_z<0>(d, a, lane);
             if (two) cp_load_z<1>(d, a1, lane);
@@ -387,18 +399,6 @@ __global__ void __launch_bounds__(64 * WPW, 2) k_wave_cp(RowCommon<float> c, CpA
         if (!two) {
 #pragma unroll
             for (int r = 0; r < 64; ++r) d[r].y = 0.f;
-        }
-        if (STEP == 1 && CONS) {
-            wave_sum<4>(acc0);
-            wave_sum<4>(acc1);
-            if (lane == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) c.partials[row0 * 4 + q] = acc0[q];
-                if (two) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) c.partials[(row0 + 1) * 4 + q] = acc1[q];
-                }
-            }
         }
         if (PROD) {
             pin(d);

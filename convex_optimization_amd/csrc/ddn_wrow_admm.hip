@@ -9,7 +9,7 @@
 template <int WPW>
 static int go(hipStream_t st, int grid, const RowCommon<float>& c, const AdmmP<float>::Args& a) {
     const size_t lds = (size_t)WPW * WFFT_TILE_FLOATS * sizeof(float);
-    if (c.do_consume && c.do_produce) return launch_row_fn(st, wrow::k_wave_row<AdmmP<float>, 2, true, true, 1, WPW>, grid, 64 * WPW, lds, c, a);
+    if (c.do_consume && c.do_produce) return launch_row_fn(st, wrow::k_wave_row<AdmmP<float>, 2, true, true, 1, WPW, 16>, grid, 64 * WPW, lds, c, a);
     if (c.do_consume) return launch_row_fn(st, wrow::k_wave_row<AdmmP<float>, 2, true, false, 1, WPW>, grid, 64 * WPW, lds, c, a);
     return launch_row_fn(st, wrow::k_wave_row<AdmmP<float>, 2, false, true, 1, WPW>, grid, 64 * WPW, lds, c, a);
 }

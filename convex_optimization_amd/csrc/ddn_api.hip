@@ -152,6 +152,7 @@ struct ddn_plan {
     // device buffers (typed by dtype)
     void* twW = nullptr;
     void* wtw = nullptr;     // per-lane twiddles of the register-resident 4096-point transform (float) or null
+    void* wtwH = nullptr;    // the same table for the H = 512 / 1024 / 2048 column transforms, or null
     void* wtwW = nullptr;    // per-lane twiddles w_W^(lane k), k < W / 64, of the W = 512 / 1024 / 2048 row transforms, or null
     void* nyqd = nullptr;    // dense home of spectral column W/2 while a solver loop runs on the wave kernels
     bool nyqd_on = false;
@@ -305,14 +306,17 @@ int plan_alloc(ddn_plan* p) {
         HIPCHK(hipMalloc(&p->wtw, tab.size() * sizeof(cx<float>)));
         HIPCHK(hipMemcpy(p->wtw, tab.data(), tab.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
     }
-    if (sizeof(T) == 4 && (p->W == 512 || p->W == 1024 || p->W == 2048)) {
-        const int R = p->W / 64;
+    for (int side = 0; side < 2; ++side) {
+        const int N = side ? p->H : p->W;
+        if (sizeof(T) != 4 || !(N == 512 || N == 1024 || N == 2048)) continue;
+        const int R = N / 64;
         std::vector<cx<float>> tab(64 * R);
-        const long double tp = -2.0L * 3.14159265358979323846264338327950288L / (long double)p->W;
+        const long double tp = -2.0L * 3.14159265358979323846264338327950288L / (long double)N;
         for (int l = 0; l < 64; ++l)
             for (int k = 0; k < R; ++k) tab[l * R + k] = {(float)cosl(tp * (l * k)), (float)sinl(tp * (l * k))};
-        HIPCHK(hipMalloc(&p->wtwW, tab.size() * sizeof(cx<float>)));
-        HIPCHK(hipMemcpy(p->wtwW, tab.data(), tab.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
+        void** dst = side ? &p->wtwH : &p->wtwW;
+        HIPCHK(hipMalloc(dst, tab.size() * sizeof(cx<float>)));
+        HIPCHK(hipMemcpy(*dst, tab.data(), tab.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
     }
     if ((rc = alloc_col_tables<T>(p))) return rc;
     if ((rc = alloc_spec<T>(p))) return rc;
@@ -398,6 +402,10 @@ inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256
 inline bool wcol_ready(const ddn_plan* p) {
     return p->eKc_ok && p->wtw && p->H == 4096 && (p->cs == 4 || p->cs == 2) && !p->injected && !getenv("DDN_NO_WAVE_COLS");
 }
+// H = 512 / 1024 / 2048: several adjacent columns per wavefront (ddn_wcoln.hpp)
+inline bool wcoln_ready(const ddn_plan* p) {
+    return p->eKc_ok && p->wtwH && (1 << p->cs) >= 4096 / p->H && p->cs <= 4 && !p->injected && !getenv("DDN_NO_WAVE_COLS");
+}
 // column-major natural-order copy of a tiled multiplier (complex and / or real)
 template <typename T>
 int make_colmajor(ddn_plan* p, const cx<T>* tiled, const T* tiled_real, void** outc, void** outr) {
@@ -418,7 +426,8 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
     constexpr int NARR = (MODE == COL_RES2) ? 2 : 1;
     if constexpr (sizeof(T) == 4 && (MODE == COL_RES2 || MODE == COL_MUL)) {
         // H = 4096: one pass, one wavefront per column (ddn_wcol.hpp)
-        if (wcol_ready(p) && mult == (const cx<T>*)p->eK && !gcplx && (MODE == COL_MUL || (greal == (const T*)p->G && p->Gcm_ok))) {
+        const bool wave1 = wcol_ready(p), waven = !wave1 && wcoln_ready(p);
+        if ((wave1 || waven) && mult == (const cx<T>*)p->eK && !gcplx && (MODE == COL_MUL || (greal == (const T*)p->G && p->Gcm_ok))) {
             wcol::Args w;
             std::memset(&w, 0, sizeof(w));
             w.S0 = (cx<float>*)p->S0; w.S1 = (cx<float>*)p->S1;
@@ -432,6 +441,10 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
             w.dbg = p->dbg ? p->dbg + 4096 * 16 : nullptr;  // second half of the stamp buffer
             w.dbg_mode = getenv("DDN_DEBUG_CMODE") ? atoi(getenv("DDN_DEBUG_CMODE")) : 0;
             TimerScope ts(p, false);
+            if (waven) {
+                w.wtw = (const cx<float>*)p->wtwH;
+                return wcoln_launch(p->stream, MODE, w);
+            }
             return wcol_launch(p->stream, MODE, w);
         }
     }
@@ -974,7 +987,7 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
 
 int ddn_plan_destroy(ddn_plan* p) {
     if (!p) return DDN_OK;
-    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->nyqd, p->eKc, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
+    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->nyqd, p->eKc, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : p->ev_pool) {
@@ -1018,7 +1031,7 @@ int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
     p->have_K = true;
     p->injected = false;
     p->eKc_ok = p->Gcm_ok = false;
-    if (p->dtype == DDN_F32 && p->wtw && p->H == 4096 && (p->cs == 4 || p->cs == 2)) {
+    if (p->dtype == DDN_F32 && ((p->wtw && p->H == 4096 && (p->cs == 4 || p->cs == 2)) || (p->wtwH && (1 << p->cs) >= 4096 / p->H && p->cs <= 4))) {
         if ((rc = make_colmajor<float>(p, (const cx<float>*)p->eK, nullptr, &p->eKc, nullptr))) return rc;
         p->eKc_ok = true;
     }

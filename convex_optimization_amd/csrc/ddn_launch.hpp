@@ -69,6 +69,8 @@ int wrown_launch(hipStream_t st, int grid, const RowCommon<float>& c, const type
 int wrown_cp_launch(hipStream_t st, int grid, const RowCommon<float>& c, const CpArgs<float>& a);
 // Wave-per-column single-pass column stage (H = 4096, float; ddn_wcol.hpp), in ddn_wcol.hip.
 int wcol_launch(hipStream_t st, int mode, const wcol::Args& a);
+// The same for H = 512, 1024, 2048 (several adjacent columns per wavefront; ddn_wcoln.hpp), in ddn_wcoln.hip.
+int wcoln_launch(hipStream_t st, int mode, const wcol::Args& a);
 
 template <typename T, class P>
 int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const RowCommon<T>& c, const typename P::Args& a) {

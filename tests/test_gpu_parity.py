@@ -386,6 +386,48 @@ def test_height_4096_wave_columns_vs_oracle(pkg, golden_dir):
         assert np.array_equal(xb[i].numpy(), xi.numpy())
 
 
+@pytest.mark.parametrize("H,W", [(512, 40), (1024, 32), (2048, 24), (1024, 1024)])
+def test_heights_512_1024_2048_wave_column_groups_vs_oracle(pkg, golden_dir, H, W):
+    """H = 512 / 1024 / 2048 float32 takes the single-pass column stage that holds 4096 / H adjacent
+    columns in one wavefront's registers (resolvent and plain multiplier form; the widths 40, 32, 24
+    end in a partly filled column group and a padded tile): K / K^T against the oracle's operators and
+    all four solvers against the CPU oracle at N = 10; 1024 x 1024 runs rows and columns on the
+    register-resident kernels together.  Two images: bit-identical to single calls."""
+    k = _load(golden_dir, "kernels.npz")
+    kern = torch.from_numpy(k["gauss9"])
+    torch.manual_seed(0)
+    img = torch.rand(1, H, W)
+    b = O.add_gaussian_noise(O.circular_convolve2d(img, kern), 0.0, 0.05)[0]
+    oo = O.DeblurDenoiseOperators(kern, b, 1, 1)
+    og = pkg.DeblurDenoiseOperators(kern, b, 1, 1, device="cuda")
+    x = torch.rand(H, W)
+    assert rel(og.apply_K(x.cuda()).real.cpu().numpy(), oo.apply_K(x).real.numpy()) < 2e-6
+    assert rel(og.apply_KTrans(x.cuda()).real.cpu().numpy(), oo.apply_KTrans(x).real.numpy()) < 2e-6
+    og.close()
+    N = 10 if W < 1024 else 4
+    torch.manual_seed(7)
+    st = (torch.rand(H, W), torch.rand(H, W), torch.rand(3, H, W))
+    xo = O.chambolle_pock(b[None], kern, max_iter=N + 1, init_state=st)
+    x = pkg.chambolle_pock_solver(b[None], kern, max_iter=N + 1, init_state=st)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    stA = tuple(torch.clamp(torch.randn(s, dtype=torch.float32), 0, 1) for s in [(H, W), (H, W), (3, H, W), (3, H, W)])
+    xo = O.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA)
+    x = pkg.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    xo = O.primal_dr_splitting("l2", kern, b, niters=N)
+    x = pkg.primal_dr_splitting("l2", kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    stP = (torch.rand(H, W), torch.rand(3, H, W))
+    xo = O.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP)
+    x = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP, tol=-1.0)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    b2 = torch.stack((b, b.flip(1)))
+    xb = pkg.primal_dual_dr_splitting(b2, kern, niters=4, init_state=(torch.stack((stP[0], stP[0])), torch.stack((stP[1], stP[1]), 1)), tol=-1.0)
+    for i in range(2):
+        xi = pkg.primal_dual_dr_splitting(b2[i], kern, niters=4, init_state=stP, tol=-1.0)
+        assert np.array_equal(xb[i].numpy(), xi.numpy())
+
+
 def test_full_size_4096_square_vs_oracle_and_tile_path(pkg, golden_dir, monkeypatch):
     """BASELINE config 3 size (4096 x 4096, motion blur): the solver loops run on the wave-per-row and
     wave-per-column kernels with spectral column W/2 in its dense side array.  Two iterations of every

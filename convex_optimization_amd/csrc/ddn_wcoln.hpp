@@ -51,15 +51,19 @@ __device__ __forceinline__ void res2_pairN(cx<float> (&d)[64], const cx<float>* 
     for (int rr = 0; rr < 32; ++rr) d[OB + rr] = mine[rr * 64 + lane];
 }
 
-template <int MODE, int R>
-__global__ void __launch_bounds__(MODE == COL_RES2 ? 128 : 64, 2) k_wave_colN(Args a) {
+// NP: column groups (wave pairs in resolvent mode) per workgroup, adjacent groups of one tile: the
+// more of a tile's 128-byte lines one CU uses, the fewer times they cross from the L2.
+template <int MODE, int R, int NP>
+__global__ void __launch_bounds__((MODE == COL_RES2 ? 128 : 64) * NP, 2) k_wave_colN(Args a) {
     constexpr int M = 64 / R;       // columns per wave
     constexpr int LM = M == 2 ? 1 : (M == 4 ? 2 : 3);
-    const int cs = a.lay.cs, gs = cs - LM;  // 2^gs column groups per tile (tiles are at least M columns wide)
-    constexpr int NT = MODE == COL_RES2 ? 128 : 64;
+    constexpr int NT = (MODE == COL_RES2 ? 128 : 64) * NP;
+    constexpr int LP = NP == 1 ? 0 : (NP == 2 ? 1 : 2);
+    const int cs = a.lay.cs, gs = cs - LM - LP;  // 2^gs workgroups per tile (tiles are at least NP M columns wide)
     extern __shared__ __align__(16) float tiles[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int h = MODE == COL_RES2 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;  // 0: S0, 1: S1
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = wv >> LP, pr = wv & (NP - 1);  // h: 0 = S0, 1 = S1; pr: the workgroup's column group
     // block -> (plane, tile, group of the tile): the G groups of a tile are 8 block indices apart
     const int per_plane = (8 << gs) * ((a.lay.ntile + 7) / 8);
     const int plane = blockIdx.x / per_plane;
@@ -68,16 +72,17 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 128 : 64, 2) k_wave_colN(Ar
     const int tile = 8 * (aa >> gs) + x, sub = aa & ((1 << gs) - 1);
     if (a.lf.enabled && b == 0) loss_finalize(a.lf, plane, reinterpret_cast<double*>(tiles), tid, NT);
     if (tile >= a.lay.ntile) return;
-    const int k2g = (tile << cs) + sub * M;  // first column of the group
-    if (k2g >= a.Wh) return;              // nothing but padding columns
+    const int k2w = (tile << cs) + sub * (M * NP);  // first column of the workgroup
+    if (k2w >= a.Wh) return;                        // nothing but padding columns
+    const int k2g = k2w + pr * M;                   // first column of the wave's group
     if (a.lf.stop) {
         const int s = a.lf.stop[plane];
         if (s >= 0 && s < a.lf.iter) return;
     }
     __syncthreads();
     cx<float>* const Sarr = (MODE == COL_RES2 && h == 1) ? a.S1 : a.S0;
-    const size_t gbase = opaque(((((size_t)plane * a.lay.ntile + tile) * a.lay.H) << cs) + (size_t)(sub * M));
-    float* const mytile = tiles + (size_t)h * WFFT_TILE_FLOATS;
+    const size_t gbase = opaque(((((size_t)plane * a.lay.ntile + tile) * a.lay.H) << cs) + (size_t)((sub * NP + pr) * M));
+    float* const mytile = tiles + (size_t)wv * WFFT_TILE_FLOATS;
     const unsigned loff = (unsigned)lane << cs;  // row `lane` of a 64-row slab, in elements
 
     // columns past the half-spectrum are tile padding: loaded, transformed and stored like the others
@@ -103,7 +108,7 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 128 : 64, 2) k_wave_colN(Ar
     if (MODE == COL_RES2) {
         const float cDd = a.cD * a.ed2[col];
         cx<float>* const mine = reinterpret_cast<cx<float>*>(mytile);
-        cx<float>* const theirs = reinterpret_cast<cx<float>*>(tiles + (size_t)(h ^ 1) * WFFT_TILE_FLOATS);
+        cx<float>* const theirs = reinterpret_cast<cx<float>*>(tiles + (size_t)(wv ^ NP) * WFFT_TILE_FLOATS);
         if (h == 0) res2_pairN<0, R>(d, a.eKc, eoff, a.cK, cDd, a.gscale, mine, theirs, lane);
         else res2_pairN<1, R>(d, a.eKc, eoff, a.cK, cDd, a.gscale, mine, theirs, lane);
     } else {

@@ -35,10 +35,12 @@ WORDS_ITER = {"chambolle_pock": 23, "primal_dr_splitting": 18, "primal_dual_dr_s
 WORDS_ROW = {"chambolle_pock": 17 / 2.0, "primal_dr_splitting": 13, "primal_dual_dr_splitting": 13, "admm_solver": 21}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # HBM bytes per launch of each fused row kernel at 4096 x 4096, one image, from the rocprofv3 PMC passes
-# whose summary is committed as profiles/r01_b_rocprofv3_summary.txt (separate --pmc runs of this
+# whose summary is committed as profiles/r01_d_rocprofv3_summary.txt (separate --pmc runs of this
 # same command): 2 x FETCH_SIZE (gfx950 reports half of the bytes of streaming reads) + WRITE_SIZE, KB -> bytes.
-MEASURED_TRAFFIC_4096 = {"k_admm_row": 2 * 387.6e6 + 713.4e6, "k_pdr_row": 2 * 226.2e6 + 363.0e6,
-                         "k_pddr_row": 2 * 226.5e6 + 363.8e6, "k_cp_row": 2 * 185.8e6 + 241.8e6}
+# Full (consume + produce) launches only; Chambolle-Pock: mean of its dual-step and primal-step kernels.
+MEASURED_TRAFFIC_4096 = {"k_admm_row": 2 * 362.1e6 + 721.3e6, "k_pdr_row": 2 * 230.9e6 + 393.7e6,
+                         "k_pddr_row": 2 * 230.9e6 + 393.6e6,
+                         "k_cp_row": (2 * 197.9e6 + 262.2e6 + 2 * 164.5e6 + 196.8e6) / 2}
 
 
 def main():

@@ -343,7 +343,9 @@ struct TimerScope {
     std::vector<EvPair>* vec;
     EvPair ev{};
     bool on;
-    TimerScope(ddn_plan* p_, bool row) : p(p_), vec(row ? &p_->ev_row : &p_->ev_col), on(p_->timing) {
+    // full = false: a launch that does only part of the steady-state work (the produce-only first and
+    // the consume-only last row launch of a loop); never sampled, so the mean is that of full launches
+    TimerScope(ddn_plan* p_, bool row, bool full = true) : p(p_), vec(row ? &p_->ev_row : &p_->ev_col), on(p_->timing && full) {
         if (on) on = (p->timing_count[row ? 0 : 1]++ % (unsigned)p->timing_stride) == 0;
         if (!on) return;
         if (p->ev_used == p->ev_pool.size()) {
@@ -579,13 +581,13 @@ inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 // and dtype, so that they compile in parallel; see ddn_launch.hpp.
 template <typename T, class P>
 int launch_solver_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, const typename P::Args& a) {
-    TimerScope ts(p, true);
+    TimerScope ts(p, true, c.do_consume && c.do_produce);
     return row_launch<T, P>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.V, c, a);
 }
 
 template <typename T>
 int launch_cp_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, const CpArgs<T>& a) {
-    TimerScope ts(p, true);
+    TimerScope ts(p, true, c.do_consume && c.do_produce);
     return cp_launch<T>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.V, c, a);
 }
 

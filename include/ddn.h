@@ -177,7 +177,9 @@ int ddn_pddr_run(ddn_plan* p, void* p_dev, void* q_dev, const void* b_dev,
 
 /* Timing hook for bench.py: average duration in milliseconds, measured with HIP
  * events on the plan's stream, of the last *_run call's dominant kernel (the fused
- * row kernel) and of all its kernels; synchronises the stream. */
+ * row kernel) and of all its kernels; synchronises the stream.  Row launches that do
+ * only part of the steady-state work (the produce-only first and the consume-only last
+ * launch of a loop) are not sampled: the row average is that of full launches. */
 int ddn_plan_last_timing(ddn_plan* p, double* row_kernel_ms_avg, double* col_kernel_ms_avg, int* n_row_launches, int* n_col_launches);
 /* on = 0: off; 1: every launch; n > 1: every n-th row launch and every n-th column launch (events cost a few
  * microseconds each, which matters when an iteration is a few hundred). */

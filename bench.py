@@ -35,7 +35,7 @@ WORDS_ITER = {"chambolle_pock": 23, "primal_dr_splitting": 18, "primal_dual_dr_s
 WORDS_ROW = {"chambolle_pock": 17 / 2.0, "primal_dr_splitting": 13, "primal_dual_dr_splitting": 13, "admm_solver": 21}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 # HBM bytes per launch of each fused row kernel at 4096 x 4096, one image, from the rocprofv3 PMC passes
-# whose summary is committed as profiles/r01_d_rocprofv3_summary.txt (separate --pmc runs of this
+# whose summary is committed under profiles/ (separate --pmc runs of this
 # same command): 2 x FETCH_SIZE (gfx950 reports half of the bytes of streaming reads) + WRITE_SIZE, KB -> bytes.
 # Full (consume + produce) launches only; Chambolle-Pock: mean of its dual-step and primal-step kernels.
 MEASURED_TRAFFIC_4096 = {"k_admm_row": 2 * 362.1e6 + 721.3e6, "k_pdr_row": 2 * 230.9e6 + 393.7e6,

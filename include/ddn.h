@@ -6,8 +6,7 @@
  * Each entry point below names the reference function(s) whose work it replaces
  * (paths relative to the reference root, deblur_denoise/...).  A Python host
  * (convex_optimization_amd/) binds these with ctypes and keeps the reference's
- * signatures; see INTEGRATION.md for the stub a maintainer of the reference
- * would add.
+ * signatures.
  *
  * Conventions
  *   - every pointer named *_dev is a device pointer (HIP), caller-owned, never

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_signatures_match_reference():
-    """The public Python signatures are the reference's (SURVEY 8b lists them): same names, order, defaults."""
+    """The public Python signatures are the reference's: same names, order, defaults."""
     import inspect
     import convex_optimization_amd as pkg
     from convex_optimization_amd.core import loss

@@ -236,7 +236,7 @@ def test_early_stop_matches_oracle(pkg, golden_dir):
 
 
 def test_config2_512_all_solvers_vs_oracle(pkg, golden_dir):
-    """512 x 512, 9x9 Gaussian + noise (BASELINE config 2): HIP path vs the CPU oracle, N = 20."""
+    """512 x 512, 9x9 Gaussian + noise (the 512 x 512 benchmark configuration): HIP path vs the CPU oracle, N = 20."""
     k = _load(golden_dir, "kernels.npz")
     kern = torch.from_numpy(k["gauss9"])
     torch.manual_seed(0)
@@ -429,7 +429,7 @@ def test_heights_512_1024_2048_wave_column_groups_vs_oracle(pkg, golden_dir, H, 
 
 
 def test_full_size_4096_square_vs_oracle_and_tile_path(pkg, golden_dir, monkeypatch):
-    """BASELINE config 3 size (4096 x 4096, motion blur): the solver loops run on the wave-per-row and
+    """The headline benchmark size (4096 x 4096, motion blur): the solver loops run on the wave-per-row and
     wave-per-column kernels with spectral column W/2 in its dense side array.  Two iterations of every
     solver against the CPU oracle, and five iterations bit-for-bit against the same kernels with that
     column left inside the tiles (the two homes hold the same numbers)."""
@@ -544,3 +544,48 @@ def test_operator_identities_at_size(pkg, golden_dir, shape):
                 ref += kk[u, v].double() * torch.roll(x, (-(u - kh // 2), -(v - kw // 2)), (0, 1))[:32, :32].double()
     assert (Kx[:32, :32].double() - ref).abs().max().item() < 3e-6
     op.close()
+
+
+@pytest.mark.parametrize("algorithm", ["chambolle_pock", "admm", "primal_dr", "primal_dual_dr"])
+def test_blur_and_deblur_image_end_to_end_vs_oracle(pkg, tmp_path, algorithm):
+    """deblur_denoise/blur_deblur.py:128-319 from an image file: read -> motion blur -> Gaussian noise ->
+    solve -> five metrics, against the same pipeline composed from the CPU oracle's pieces under the
+    same seed (the noise and the solver's initial iterates come from torch's CPU generator in the
+    same order).  The file read is this build's own (Pillow decode, then the reference's arithmetic)."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    yy, xx = np.mgrid[0:90, 0:120]
+    base = 0.5 + 0.4 * np.sin(xx / 9.0) * np.cos(yy / 7.0)
+    rgb = np.clip((base[..., None] * np.array([1.0, 0.8, 0.6]) + 0.05 * rng.standard_normal((90, 120, 3))) * 255, 0, 255).astype(np.uint8)
+    path = str(tmp_path / "scene.png")
+    Image.fromarray(rgb).save(path)
+    shape = (64, 64)
+    N = 12
+    par = dict(chambolle_pock=dict(t=0.4, s=0.7, rho=0.4, gamma=0.01), admm=dict(t=18, s=0.7, rho=0.001, gamma=0.5),
+               primal_dr=dict(t=2.0, s=0.7, rho=0.1, gamma=0.049), primal_dual_dr=dict(t=3, s=0.7, rho=0.4, gamma=0.03))[algorithm]
+    torch.manual_seed(11)
+    x = pkg.blur_and_deblur_image(path, image_shape=shape, blur_type="motion", blur_kernel_size=7, blur_kernel_angle=30,
+                                  noise_type="gaussian", mean=0.0, std=0.05, algorithm=algorithm, niters=N,
+                                  loss_function=pkg.core.psnr, **par)
+    got = dict(pkg.blur_deblur.last_metrics)
+
+    img = pkg.utils.conv_utils.read_image(path, shape=shape)
+    kern = O.create_motion_blur_kernel(7, 30)
+    torch.manual_seed(11)
+    b = O.add_gaussian_noise(O.circular_convolve2d(img, kern), 0.0, 0.05).squeeze()
+    if algorithm == "chambolle_pock":
+        xo = O.chambolle_pock(b.unsqueeze(0), kern, t=par["t"], s=par["s"], gamma=par["gamma"], max_iter=N)
+    elif algorithm == "admm":
+        xo = O.admm_solver(b, kernel=kern, t=par["t"], rho=par["rho"], gamma=par["gamma"], niters=N, tol=1e-4)
+    elif algorithm == "primal_dr":
+        xo = O.primal_dr_splitting("primal_dr", kern, b, t=par["t"], gamma=par["gamma"], rho=par["rho"], tol=1e-6, niters=N)
+    else:
+        xo = O.primal_dual_dr_splitting(b, kern, niters=N, t=par["t"], rho=par["rho"], gamma=par["gamma"], tol=1e-6)
+    xo = torch.as_tensor(xo)
+    assert tuple(x.shape) == tuple(xo.shape)
+    assert rel(x.numpy(), xo.numpy()) < 1e-5
+    o2, x2 = img.squeeze(0), xo.squeeze(0) if xo.dim() == 3 else xo
+    exp = {"psnr": float(O.psnr(x2, o2)), "ssim": float(torch.as_tensor(O.ssim(x2, o2)).squeeze()), "mse": float(O.mse(x2, o2)),
+           "l1_loss": float(O.l1_loss(x2, o2)), "l2_loss": float(O.l2_loss(x2, o2))}
+    for k, v in exp.items():
+        assert abs(got[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, got[k], v)

@@ -589,3 +589,34 @@ def test_blur_and_deblur_image_end_to_end_vs_oracle(pkg, tmp_path, algorithm):
            "l1_loss": float(O.l1_loss(x2, o2)), "l2_loss": float(O.l2_loss(x2, o2))}
     for k, v in exp.items():
         assert abs(got[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, got[k], v)
+
+
+@pytest.mark.parametrize("H,W", [(16, 1024), (1024, 16), (16, 4096)])
+def test_early_stop_on_register_resident_kernels(pkg, golden_dir, H, W):
+    """The per-image stop flag on the wave-per-row(-group) and wave-per-column(-group) kernels: primal
+    DR stops at the oracle's iteration with the oracle's iterate, and in a batch of two images each
+    freezes at its own iteration (bit-identical to the single-image runs)."""
+    k = _load(golden_dir, "kernels.npz")
+    kern = torch.from_numpy(k["gauss9"])
+    torch.manual_seed(0)
+    img = torch.rand(2, H, W)
+    b2 = O.add_gaussian_noise(O.circular_convolve2d(img, kern), 0.0, 0.05)
+    b2[1] = 0.1 * b2[1] + 0.45      # a flatter second image: its loss runs about 9 % below the first one's
+    trajs = []
+    for i in range(2):
+        trajs.append([])
+        O.primal_dr_splitting("l1", kern, b2[i], niters=14, loss_function=O.mse, tol=-1.0, losses=trajs[i])
+    tol = 0.5 * (float(trajs[0][7]) + float(trajs[1][7]))   # between the two: the images stop one iteration apart
+    assert float(trajs[1][7]) < 0.97 * float(trajs[0][7])
+    counts, singles = [], []
+    for i in range(2):
+        ol = []
+        xo = O.primal_dr_splitting("l1", kern, b2[i], niters=14, loss_function=O.mse, tol=tol, losses=ol)
+        x, losses = pkg.primal_dr_splitting("l1", kern, b2[i], niters=14, loss_function=pkg.core.mse, tol=tol, return_losses=True)
+        assert len(losses) == len(ol)
+        assert rel(x.numpy(), xo.numpy()) < 1e-5
+        counts.append(len(ol)); singles.append(x)
+    assert counts[0] < 14 and counts[0] != counts[1]
+    xb = pkg.primal_dr_splitting("l1", kern, b2, niters=14, loss_function=pkg.core.mse, tol=tol)
+    for i in range(2):
+        assert np.array_equal(xb[i].numpy(), singles[i].numpy())

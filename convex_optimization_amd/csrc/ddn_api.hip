@@ -156,6 +156,7 @@ struct ddn_plan {
     void* wtwW = nullptr;    // per-lane twiddles w_W^(lane k), k < W / 64, of the W = 512 / 1024 / 2048 row transforms, or null
     void* nyqd = nullptr;    // dense home of spectral column W/2 while a solver loop runs on the wave kernels
     bool nyqd_on = false;
+    bool ilv_on = false;     // a solver loop runs with S0 / S1 interleaved element by element in the S0 block (wave kernels)
     void* eKc = nullptr;     // column-major natural-order copies of eK and G for the wave-per-column stage
     void* Gcm = nullptr;
     bool eKc_ok = false, Gcm_ok = false;
@@ -254,16 +255,17 @@ bool choose_col(ddn_plan* p) {
 
 template <typename T>
 int alloc_spec(ddn_plan* p) {
-    void** bufs[] = {&p->S0, &p->S1, &p->eK, &p->G, &p->Gc, &p->tmp_mult};
+    void** bufs[] = {&p->S0, &p->eK, &p->G, &p->Gc, &p->tmp_mult};
     for (void** q : bufs) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
     }
+    // S0 and S1 are the two halves of ONE allocation: the wave kernels of the resolvent solvers use the
+    // same memory as one array of (S0, S1) pairs
     const size_t spec = (size_t)p->batch * p->spec_plane * sizeof(cx<T>);
-    HIPCHK(hipMalloc(&p->S0, spec));
-    HIPCHK(hipMalloc(&p->S1, spec));
-    HIPCHK(hipMemset(p->S0, 0, spec));
-    HIPCHK(hipMemset(p->S1, 0, spec));
+    HIPCHK(hipMalloc(&p->S0, 2 * spec));
+    p->S1 = (char*)p->S0 + spec;
+    HIPCHK(hipMemset(p->S0, 0, 2 * spec));
     const size_t m = p->spec_plane;
     HIPCHK(hipMalloc(&p->eK, m * sizeof(cx<T>)));
     HIPCHK(hipMalloc(&p->G, m * sizeof(T)));
@@ -440,6 +442,7 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
             w.nyq_packed = (p->W % 2 == 0 && getenv("DDN_NYQ_PACK")) ? 1 : 0;
             w.conj_mult = conj_mult; w.scale = (float)scale; w.lf = lf;
             w.nyqd = p->nyqd_on ? (float*)p->nyqd : nullptr;
+            w.ilv = (p->ilv_on && MODE == COL_RES2) ? 1 : 0;
             w.dbg = p->dbg ? p->dbg + 4096 * 16 : nullptr;  // second half of the stamp buffer
             w.dbg_mode = getenv("DDN_DEBUG_CMODE") ? atoi(getenv("DDN_DEBUG_CMODE")) : 0;
             TimerScope ts(p, false);
@@ -560,6 +563,7 @@ RowCommon<T> row_common(ddn_plan* p, int V, bool consume, bool produce) {
     c.V_groups = V ? p->W / V : 0;
     c.wtw = (const cx<T>*)(p->W == 4096 ? p->wtw : p->wtwW);
     c.nyqd = p->nyqd_on ? (T*)p->nyqd : nullptr;
+    c.ilv = p->ilv_on ? 1 : 0;
     c.fw = p->fw;
     c.lay = layout_of(p);
     c.twW = (const cx<T>*)p->twW;
@@ -751,13 +755,18 @@ int set_resolvent_impl(ddn_plan* p, double cK, double cD, const void* M_dev, int
 // array instead of the last tile (where it would use 8 bytes of every 128-byte line).
 struct NyqDense {
     ddn_plan* p;
-    NyqDense(ddn_plan* p_, bool wave_rows) : p(p_) {
+    // res2: a resolvent-mode solver (pdr, pddr, admm), whose row and column kernels both move S0 and S1
+    NyqDense(ddn_plan* p_, bool wave_rows, bool res2 = false) : p(p_) {
         p->nyqd_on = false;
-        if (!wave_rows || p->W != 4096 || !wcol_ready(p) || p->W % 2 || (p->Wh & 3) != 1 || getenv("DDN_NO_NYQ_DENSE")) return;
+        p->ilv_on = false;
+        if (!wave_rows || p->W != 4096 || !wcol_ready(p) || p->W % 2 || (p->Wh & 3) != 1) return;
+        // both stages on the wave kernels: interleave the two half-spectra (16-column tiles only)
+        p->ilv_on = res2 && p->cs == 4 && p->Gcm_ok && !getenv("DDN_NYQ_PACK") && !getenv("DDN_NO_ILV");
+        if (getenv("DDN_NO_NYQ_DENSE")) return;
         if (!p->nyqd && hipMalloc(&p->nyqd, sizeof(float) * 2 * (size_t)p->batch * p->H) != hipSuccess) { p->nyqd = nullptr; return; }
         p->nyqd_on = true;
     }
-    ~NyqDense() { p->nyqd_on = false; }
+    ~NyqDense() { p->nyqd_on = false; p->ilv_on = false; }
 };
 
 // ----------------------------------------------------------------------------- solver loops
@@ -769,7 +778,7 @@ int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, doubl
     RowCfg cfg;
     const bool al = aligned16(z1) && aligned16(z2) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
-    NyqDense nyq_guard(p, cfg.V == 0);
+    NyqDense nyq_guard(p, cfg.V == 0, true);
     typename PdrP<T>::Args a;
     RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
@@ -800,7 +809,7 @@ int pddr_run_impl(ddn_plan* p, void* pp, void* q, const void* b, double t, doubl
     RowCfg cfg;
     const bool al = aligned16(pp) && aligned16(q) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
-    NyqDense nyq_guard(p, cfg.V == 0);
+    NyqDense nyq_guard(p, cfg.V == 0, true);
     typename PddrP<T>::Args a;
     RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
@@ -832,7 +841,7 @@ int admm_run_impl(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b
     RowCfg cfg;
     const bool al = aligned16(u) && aligned16(w) && aligned16(y) && aligned16(z) && aligned16(b) && aligned16(sol) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
-    NyqDense nyq_guard(p, cfg.V == 0);
+    NyqDense nyq_guard(p, cfg.V == 0, true);
     typename AdmmP<T>::Args a;
     RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
@@ -989,7 +998,7 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
 
 int ddn_plan_destroy(ddn_plan* p) {
     if (!p) return DDN_OK;
-    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->nyqd, p->eKc, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->S1, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
+    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->nyqd, p->eKc, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : p->ev_pool) {

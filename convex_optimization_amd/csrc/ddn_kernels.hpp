@@ -437,6 +437,7 @@ struct RowCommon {
     const int* stop;     // per image, may be null
     double* partials;    // [batch*H][4]
     int do_consume, do_produce;
+    int ilv;             // S0 holds the (S0, S1) pairs interleaved element by element (wave kernels only); S1 unused
     long long* dbg;      // diagnostic builds only: per-workgroup phase stamps (null = off)
     int dbg_mode;        // diagnostic: bit0 skip the transforms, bit1 skip pack/unpack, bit2 skip iterate stores
 };

@@ -75,6 +75,69 @@ __device__ __forceinline__ void store_quarter(const cx<float> (&d)[64], cx<float
     }
 }
 
+// The same for interleaved half-spectra (pairs (S0, S1) of 16 bytes): the eight waves of the
+// workgroup load the quarter's rows together -- a wave instruction covers 16 rows x 64 contiguous
+// bytes, waves 0-3 the even slabs and waves 4-7 the odd ones, 32 loads per lane -- and hand the S0
+// parts to the column owners of half 0 (through stg0), the S1 parts to those of half 1 (stg1).
+// A loaded pair occupies the registers of d[2 i], d[2 i + 1] until its round.
+// base: the pair array offset to (row 0, first column of the quarter), in pairs.
+__device__ __forceinline__ void load_quarter_ilv(cx<float> (&d)[64], const wrow::f4* base, int rpitch, cx<float>* stg0, cx<float>* stg1, int wv, int lane) {
+    const int wq = wv & 3, hh = wv >> 2;
+    const int rl = 16 * wq + (lane >> 2), cl = lane & 3;
+    const unsigned goff = (unsigned)(rl * rpitch + cl);
+    const int wr = 4 * rl + cl + (rl >> 2);
+    const int rd = 4 * lane + wq + (lane >> 2);
+    const cx<float>* const mystg = hh ? stg1 : stg0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const wrow::f4 v = (base + (size_t)(64 * (2 * i + hh)) * rpitch)[goff];
+        d[2 * i] = mk<float>(v.x, v.y);
+        d[2 * i + 1] = mk<float>(v.z, v.w);
+    }
+    sched_fence();
+#pragma unroll
+    for (int round = 0; round < 64 / kSlabs; ++round) {
+#pragma unroll
+        for (int ii = 0; ii < kSlabs / 2; ++ii) {
+            stg0[(2 * ii + hh) * kSlabPitch + wr] = d[round * kSlabs + 2 * ii];
+            stg1[(2 * ii + hh) * kSlabPitch + wr] = d[round * kSlabs + 2 * ii + 1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < kSlabs; ++s) d[round * kSlabs + s] = mystg[s * kSlabPitch + rd];
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void store_quarter_ilv(const cx<float> (&d)[64], wrow::f4* base, int rpitch, cx<float>* stg0, cx<float>* stg1, int wv, int lane, int ncols) {
+    const int wq = wv & 3, hh = wv >> 2;
+    const int rl = 16 * wq + (lane >> 2), cl = lane & 3;
+    const unsigned goff = (unsigned)(rl * rpitch + cl);
+    const int wr = 4 * rl + cl + (rl >> 2);
+    const int rd = 4 * lane + wq + (lane >> 2);
+    cx<float>* const mystg = hh ? stg1 : stg0;
+#pragma unroll
+    for (int round = 0; round < 64 / kSlabs; ++round) {
+#pragma unroll
+        for (int s = 0; s < kSlabs; ++s) mystg[s * kSlabPitch + rd] = d[round * kSlabs + s];
+        __syncthreads();
+        cx<float> t0[kSlabs / 2], t1[kSlabs / 2];
+#pragma unroll
+        for (int ii = 0; ii < kSlabs / 2; ++ii) {
+            t0[ii] = stg0[(2 * ii + hh) * kSlabPitch + wr];
+            t1[ii] = stg1[(2 * ii + hh) * kSlabPitch + wr];
+        }
+        if (cl < ncols) {
+#pragma unroll
+            for (int ii = 0; ii < kSlabs / 2; ++ii) {
+                wrow::f4 v;
+                v.x = t0[ii].x; v.y = t0[ii].y; v.z = t1[ii].x; v.w = t1[ii].y;
+                (base + (size_t)(64 * (round * kSlabs + 2 * ii + hh)) * rpitch)[goff] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Pointwise stage of the resolvent mode for the wave pair (A = S0 column, B = S1 column):
 //   U = (P + conj(e) Q) g,  V = e U,   A must end with U, B with V.
 // The work is split by register halves: wave HH finishes registers 32 HH .. 32 HH + 31 (it loads
@@ -204,8 +267,9 @@ __device__ __forceinline__ void mul_packed(cx<float> (&d)[64], const cx<float>* 
 }
 
 // MODE: COL_RES2 (eight waves: four columns of S0 and of S1) or COL_MUL (four waves: four columns of S0)
-template <int MODE, bool PACKED>
+template <int MODE, bool PACKED, bool ILV = false>
 __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Args a) {
+    static_assert(!ILV || (MODE == COL_RES2 && !PACKED), "interleaved spectra: resolvent mode, plain columns");
     extern __shared__ __align__(16) float tiles[];
     constexpr int NT = MODE == COL_RES2 ? 512 : 256;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -241,6 +305,8 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
     cx<float>* const Sarr = (MODE == COL_RES2 && h == 1) ? a.S1 : a.S0;
     const size_t qbase = opaque(((((size_t)plane * a.lay.ntile + (k2q >> cs)) * a.lay.H) << cs) + (k2q & (C - 1)));
     cx<float>* const stg = reinterpret_cast<cx<float>*>(tiles + (size_t)(4 * h) * WFFT_TILE_FLOATS);
+    cx<float>* const stg0 = reinterpret_cast<cx<float>*>(tiles);
+    cx<float>* const stg1 = reinterpret_cast<cx<float>*>(tiles + (size_t)4 * WFFT_TILE_FLOATS);
     float* const mytile = tiles + (size_t)wv * WFFT_TILE_FLOATS;
 
     // column W/2 with a dense home: its quarter holds nothing else, so the workgroup skips the tile traffic
@@ -254,6 +320,8 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
     if (dense) {
 #pragma unroll
         for (int r = 0; r < 64; ++r) d[r] = mk<float>(wq == 0 ? dcol[64 * r + lane] : 0.f, 0.f);
+    } else if (ILV) {
+        load_quarter_ilv(d, reinterpret_cast<const wrow::f4*>(a.S0) + qbase, C, stg0, stg1, wv, lane);
     } else if ((cs == 2 && !(a.dbg_mode & 16)) || (cs != 2 && (a.dbg_mode & 64))) {
         // 4-column tiles: the quarter is one contiguous block of rows x 4 columns; each wave reads its
         // own column directly (32-byte stride; the four waves of a half use every byte of every line)
@@ -336,6 +404,8 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
 #pragma unroll
             for (int r = 0; r < 64; ++r) dcol[64 * r + lane] = d[r].x;
         }
+    } else if (ILV) {
+        store_quarter_ilv(d, reinterpret_cast<wrow::f4*>(a.S0) + opaque(qbase), C, stg0, stg1, wv, lane, ncols);
     } else if (cs == 2 && (a.dbg_mode & 32)) {  // direct stores measured slower than the staged ones: diagnostic only
         if (wq < ncols) {
             cx<float>* const colp = Sarr + opaque(qbase) + wq;

@@ -25,6 +25,7 @@ struct Args {
     float scale;
     LossFin lf;
     long long* dbg;        // diagnostic: per-workgroup phase stamps (16 per workgroup) or null
+    int ilv;               // resolvent mode: S0 holds the (S0, S1) pairs interleaved element by element
     int dbg_mode;          // diagnostic ablations (results wrong by construction): bit0 no multiplier loads, bit1 no exchange, bit2 every slab reads slab 0
 };
 

@@ -69,16 +69,41 @@ __device__ __forceinline__ size_t spec_row_base(const SpecLayout& l, int plane, 
 
 // Merge: half-spectra A = F(a), B = F(b), k = 0..2048, of two real rows -> spectrum of a + i b.
 // rowA / rowB: the arrays already offset to the row (uniform); TWO = false: b = 0.
-template <bool TWO>
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ILV: the two half-spectra are interleaved element by element in ONE array (A[k], B[k] adjacent, 16
+// bytes): rowA points at the pair array offset to the row (in pairs), rowB is unused.  A lane then
+// moves both spectra of a frequency with one 16-byte access, and the column stage, whose workgroup
+// owns 4 columns of both spectra, finds them in 64 contiguous bytes of a row instead of 2 x 32.
+template <bool TWO, bool ILV = false>
 __device__ __forceinline__ void pack(cx<float> (&d)[64], const cx<float>* rowA, const cx<float>* rowB, const SpecAddr& sa, int lane, const float* nyqA = nullptr, const float* nyqB = nullptr) {
+    cx<float> Un, Vn;
+    if (ILV) {
+        const f4* const q = reinterpret_cast<const f4*>(rowA);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
-        d[r] = (rowA + r * sa.rstride)[sa.lane_off];                         // A[k], k = 64 r + lane
-        d[63 - r] = TWO ? (rowB + r * sa.rstride)[sa.lane_off] : mk<float>(0.f, 0.f);  // B[k]
+        for (int r = 0; r < 32; ++r) {
+            const f4 v = (q + r * sa.rstride)[sa.lane_off];
+            d[r] = mk<float>(v.x, v.y);
+            d[63 - r] = mk<float>(v.z, v.w);
+        }
+        if (nyqA) {
+            Un = mk<float>(*nyqA, 0.f);
+            Vn = mk<float>(*nyqB, 0.f);
+        } else {
+            const f4 v = q[sa.nyq];
+            Un = mk<float>(v.x, v.y);
+            Vn = mk<float>(v.z, v.w);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            d[r] = (rowA + r * sa.rstride)[sa.lane_off];                         // A[k], k = 64 r + lane
+            d[63 - r] = TWO ? (rowB + r * sa.rstride)[sa.lane_off] : mk<float>(0.f, 0.f);  // B[k]
+        }
+        // column W/2 (real): from its dense home when there is one, else from the last tile
+        Un = nyqA ? mk<float>(*nyqA, 0.f) : rowA[sa.nyq];
+        Vn = TWO ? (nyqB ? mk<float>(*nyqB, 0.f) : rowB[sa.nyq]) : mk<float>(0.f, 0.f);
     }
-    // column W/2 (real): from its dense home when there is one, else from the last tile
-    const cx<float> Un = nyqA ? mk<float>(*nyqA, 0.f) : rowA[sa.nyq];
-    const cx<float> Vn = TWO ? (nyqB ? mk<float>(*nyqB, 0.f) : rowB[sa.nyq]) : mk<float>(0.f, 0.f);
     sched_fence();
     const int ml = (64 - lane) & 63;
     const float u0 = d[0].x, v0 = d[63].x;
@@ -104,9 +129,10 @@ __device__ __forceinline__ void pack(cx<float> (&d)[64], const cx<float>* rowA, 
 }
 
 // Split: spectrum Z of a + i b -> half-spectra of a (to rowA) and b (to rowB when TWO).
-template <bool TWO>
+template <bool TWO, bool ILV = false>
 __device__ __forceinline__ void unpack(const cx<float> (&d)[64], cx<float>* rowA, cx<float>* rowB, const SpecAddr& sa, int lane, float* nyqA = nullptr, float* nyqB = nullptr) {
     const int ml = (64 - lane) & 63;
+    f4* const q = reinterpret_cast<f4*>(rowA);
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
         cx<float> Zm = mk<float>(lane_get(d[63 - r].x, ml), lane_get(d[63 - r].y, ml));
@@ -114,13 +140,31 @@ __device__ __forceinline__ void unpack(const cx<float> (&d)[64], cx<float>* rowA
         Zm.x = lane == 0 ? own.x : Zm.x;
         Zm.y = lane == 0 ? own.y : Zm.y;
         const cx<float> Z = d[r];
-        (rowA + r * sa.rstride)[sa.lane_off] = mk<float>(0.5f * (Z.x + Zm.x), 0.5f * (Z.y - Zm.y));
-        if (TWO) (rowB + r * sa.rstride)[sa.lane_off] = mk<float>(0.5f * (Z.y + Zm.y), 0.5f * (Zm.x - Z.x));
+        if (ILV) {
+            f4 v;
+            v.x = 0.5f * (Z.x + Zm.x); v.y = 0.5f * (Z.y - Zm.y);
+            v.z = 0.5f * (Z.y + Zm.y); v.w = 0.5f * (Zm.x - Z.x);
+            (q + r * sa.rstride)[sa.lane_off] = v;
+        } else {
+            (rowA + r * sa.rstride)[sa.lane_off] = mk<float>(0.5f * (Z.x + Zm.x), 0.5f * (Z.y - Zm.y));
+            if (TWO) (rowB + r * sa.rstride)[sa.lane_off] = mk<float>(0.5f * (Z.y + Zm.y), 0.5f * (Zm.x - Z.x));
+        }
     }
     if (lane == 0) {
-        if (nyqA) *nyqA = d[32].x; else rowA[sa.nyq] = mk<float>(d[32].x, 0.f);
-        if (TWO) {
-            if (nyqB) *nyqB = d[32].y; else rowB[sa.nyq] = mk<float>(d[32].y, 0.f);
+        if (ILV) {
+            if (nyqA) {
+                *nyqA = d[32].x;
+                *nyqB = d[32].y;
+            } else {
+                f4 v;
+                v.x = d[32].x; v.y = 0.f; v.z = d[32].y; v.w = 0.f;
+                q[sa.nyq] = v;
+            }
+        } else {
+            if (nyqA) *nyqA = d[32].x; else rowA[sa.nyq] = mk<float>(d[32].x, 0.f);
+            if (TWO) {
+                if (nyqB) *nyqB = d[32].y; else rowB[sa.nyq] = mk<float>(d[32].y, 0.f);
+            }
         }
     }
 }
@@ -162,7 +206,7 @@ __device__ __forceinline__ A at_reg(const A& a, int r) {
 // ----------------------------------------------------------------------------------------------
 // PDR / PDDR / ADMM: the policies of ddn_kernels.hpp, one pixel per register.
 // PD = depth of the iterate-array load pipeline (registers r .. r+PD-1 are in flight).
-template <class P, int PD, bool CONS, bool PROD, int FE = 1, int WPW = 1, int SP = 0>
+template <class P, int PD, bool CONS, bool PROD, int FE = 1, int WPW = 1, int SP = 0, bool ILV = false>
 #ifndef WROW_MINW
 #define WROW_MINW 2
 #endif
@@ -186,14 +230,14 @@ __global__ void __launch_bounds__(64 * WPW, WROW_MINW) k_wave_row(RowCommon<floa
         typename P::Args a = a0;
         advance(a, opaque((size_t)row * 4096));
         const size_t sbase = opaque(spec_row_base(c.lay, plane, row - plane * c.H));
-        cx<float>* const row0 = c.S0 + sbase;
+        cx<float>* const row0 = c.S0 + (ILV ? 2 : 1) * sbase;  // ILV: S0 holds the (S0, S1) pairs, 16 bytes each
         cx<float>* const row1 = c.S1 + sbase;
         const unsigned ul = (unsigned)lane;
         float* const nq0 = c.nyqd ? c.nyqd + ((size_t)plane * 2 * c.H + (row - plane * c.H)) : nullptr;
         float* const nq1 = c.nyqd ? nq0 + c.H : nullptr;
         cx<float> d[64];
         if (CONS) {
-            pack<true>(d, row0, row1, sa, lane, nq0, nq1);
+            pack<true, ILV>(d, row0, row1, sa, lane, nq0, nq1);
             wfft::fft4096<true>(d, c.wtw, tile, lane);
             pin(d);
         } else {
@@ -246,7 +290,7 @@ __global__ void __launch_bounds__(64 * WPW, WROW_MINW) k_wave_row(RowCommon<floa
             sched_fence();
             wfft::fft4096<false>(d, c.wtw, tile, lane);
             pin(d);
-            unpack<true>(d, row0, row1, sa, lane, nq0, nq1);
+            unpack<true, ILV>(d, row0, row1, sa, lane, nq0, nq1);
         }
     }
 }

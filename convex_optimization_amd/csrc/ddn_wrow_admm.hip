@@ -14,7 +14,16 @@ static int go(hipStream_t st, int grid, const RowCommon<float>& c, const AdmmP<f
     return launch_row_fn(st, wrow::k_wave_row<AdmmP<float>, 2, false, true, 1, WPW>, grid, 64 * WPW, lds, c, a);
 }
 
+// interleaved half-spectra (16-column tiles only)
+static int go_ilv(hipStream_t st, int grid, const RowCommon<float>& c, const AdmmP<float>::Args& a) {
+    const size_t lds = (size_t)WFFT_TILE_FLOATS * sizeof(float);
+    if (c.do_consume && c.do_produce) return launch_row_fn(st, wrow::k_wave_row<AdmmP<float>, 2, true, true, 1, 1, 16, true>, grid, 64, lds, c, a);
+    if (c.do_consume) return launch_row_fn(st, wrow::k_wave_row<AdmmP<float>, 2, true, false, 1, 1, 0, true>, grid, 64, lds, c, a);
+    return launch_row_fn(st, wrow::k_wave_row<AdmmP<float>, 2, false, true, 1, 1, 0, true>, grid, 64, lds, c, a);
+}
+
 template <>
 int wrow_launch<AdmmP<float>>(hipStream_t st, int grid, const RowCommon<float>& c, const AdmmP<float>::Args& a) {
+    if (c.ilv) return c.lay.cs == 4 ? go_ilv(st, grid, c, a) : DDN_E_UNSUPPORTED;
     return c.lay.cs == 2 ? go<4>(st, grid, c, a) : go<1>(st, grid, c, a);
 }

@@ -14,7 +14,16 @@ static int go(hipStream_t st, int grid, const RowCommon<float>& c, const PdrP<fl
     return launch_row_fn(st, wrow::k_wave_row<PdrP<float>, 8, false, true, 1, WPW>, grid, 64 * WPW, lds, c, a);
 }
 
+// interleaved half-spectra (16-column tiles only)
+static int go_ilv(hipStream_t st, int grid, const RowCommon<float>& c, const PdrP<float>::Args& a) {
+    const size_t lds = (size_t)WFFT_TILE_FLOATS * sizeof(float);
+    if (c.do_consume && c.do_produce) return launch_row_fn(st, wrow::k_wave_row<PdrP<float>, 8, true, true, 2, 1, 0, true>, grid, 64, lds, c, a);
+    if (c.do_consume) return launch_row_fn(st, wrow::k_wave_row<PdrP<float>, 8, true, false, 1, 1, 0, true>, grid, 64, lds, c, a);
+    return launch_row_fn(st, wrow::k_wave_row<PdrP<float>, 8, false, true, 1, 1, 0, true>, grid, 64, lds, c, a);
+}
+
 template <>
 int wrow_launch<PdrP<float>>(hipStream_t st, int grid, const RowCommon<float>& c, const PdrP<float>::Args& a) {
+    if (c.ilv) return c.lay.cs == 4 ? go_ilv(st, grid, c, a) : DDN_E_UNSUPPORTED;
     return c.lay.cs == 2 ? go<4>(st, grid, c, a) : go<1>(st, grid, c, a);
 }

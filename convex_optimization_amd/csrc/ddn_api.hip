@@ -759,10 +759,10 @@ struct NyqDense {
     NyqDense(ddn_plan* p_, bool wave_rows, bool res2 = false) : p(p_) {
         p->nyqd_on = false;
         p->ilv_on = false;
-        if (!wave_rows || p->W != 4096 || !wcol_ready(p) || p->W % 2 || (p->Wh & 3) != 1) return;
-        // both stages on the wave kernels: interleave the two half-spectra (16-column tiles only)
-        p->ilv_on = res2 && p->cs == 4 && p->Gcm_ok && !getenv("DDN_NYQ_PACK") && !getenv("DDN_NO_ILV");
-        if (getenv("DDN_NO_NYQ_DENSE")) return;
+        if (!wave_rows) return;
+        // both stages on the wave kernels: interleave the two half-spectra (not with 4-column tiles)
+        p->ilv_on = res2 && (wcol_ready(p) || wcoln_ready(p)) && p->cs > 2 && p->Gcm_ok && !getenv("DDN_NYQ_PACK") && !getenv("DDN_NO_ILV");
+        if (p->W != 4096 || !wcol_ready(p) || p->W % 2 || (p->Wh & 3) != 1 || getenv("DDN_NO_NYQ_DENSE")) return;
         if (!p->nyqd && hipMalloc(&p->nyqd, sizeof(float) * 2 * (size_t)p->batch * p->H) != hipSuccess) { p->nyqd = nullptr; return; }
         p->nyqd_on = true;
     }

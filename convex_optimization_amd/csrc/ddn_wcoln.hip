@@ -3,13 +3,13 @@
 #include "ddn_launch.hpp"
 #include "ddn_wcoln.hpp"
 
-template <int MODE, int R, int NP>
+template <int MODE, int R, int NP, bool ILV = false>
 static int wcoln_go1(hipStream_t st, const wcol::Args& a) {
     constexpr int waves = (MODE == COL_RES2 ? 2 : 1) * NP;
     constexpr int M = 64 / R;
     if ((1 << a.lay.cs) < M * NP || a.lay.cs > 4) return DDN_E_UNSUPPORTED;
     const int G = (1 << a.lay.cs) / (M * NP);
-    auto fn = wcol::k_wave_colN<MODE, R, NP>;
+    auto fn = wcol::k_wave_colN<MODE, R, NP, ILV>;
     int rc = ensure_lds_attr((const void*)fn);
     if (rc) return rc;
     const int grid = a.batch * 8 * G * ((a.lay.ntile + 7) / 8);
@@ -24,6 +24,12 @@ static int wcoln_go(hipStream_t st, const wcol::Args& a) {
     // H = 2048 (16 bytes of a line per group).  DDN_COLN_NP overrides, for measurements.
     static const int np = getenv("DDN_COLN_NP") ? atoi(getenv("DDN_COLN_NP")) : (R == 32 ? 2 : 1);
     constexpr int M = 64 / R;
+    if constexpr (MODE == COL_RES2) {
+        if (a.ilv) {
+            if (np >= 2 && (1 << a.lay.cs) >= 2 * M) return wcoln_go1<MODE, R, 2, true>(st, a);
+            return wcoln_go1<MODE, R, 1, true>(st, a);
+        }
+    }
     if (np == 4 && (1 << a.lay.cs) >= 4 * M) return wcoln_go1<MODE, R, 4>(st, a);
     if (np >= 2 && (1 << a.lay.cs) >= 2 * M) return wcoln_go1<MODE, R, 2>(st, a);
     return wcoln_go1<MODE, R, 1>(st, a);

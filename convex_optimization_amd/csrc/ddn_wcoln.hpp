@@ -53,8 +53,13 @@ __device__ __forceinline__ void res2_pairN(cx<float> (&d)[64], const cx<float>* 
 
 // NP: column groups (wave pairs in resolvent mode) per workgroup, adjacent groups of one tile: the
 // more of a tile's 128-byte lines one CU uses, the fewer times they cross from the L2.
-template <int MODE, int R, int NP>
+// ILV (resolvent mode): S0 holds the (S0, S1) pairs interleaved element by element, so the M columns of
+// both spectra are 16 M contiguous bytes of a row.  Each wave of a pair then loads whole pairs for
+// half of the rows (wave 0 the first R / 2 slabs of 64 rows, wave 1 the rest) and the two swap the
+// halves they loaded for each other through their tiles; the store mirrors it.
+template <int MODE, int R, int NP, bool ILV = false>
 __global__ void __launch_bounds__((MODE == COL_RES2 ? 128 : 64) * NP, 2) k_wave_colN(Args a) {
+    static_assert(!ILV || MODE == COL_RES2, "interleaved spectra: resolvent mode only");
     constexpr int M = 64 / R;       // columns per wave
     constexpr int LM = M == 2 ? 1 : (M == 4 ? 2 : 3);
     constexpr int NT = (MODE == COL_RES2 ? 128 : 64) * NP;
@@ -88,14 +93,58 @@ __global__ void __launch_bounds__((MODE == COL_RES2 ? 128 : 64) * NP, 2) k_wave_
     // columns past the half-spectrum are tile padding: loaded, transformed and stored like the others
     // (their values are never read by a row kernel), with the multipliers of the last real column
     cx<float> d[64];
+    if (ILV) {
+        cx<float>* const mine = reinterpret_cast<cx<float>*>(mytile);
+        cx<float>* const theirs = reinterpret_cast<cx<float>*>(tiles + (size_t)(wv ^ NP) * WFFT_TILE_FLOATS);
+        const f4* const pairs = reinterpret_cast<const f4*>(a.S0) + gbase;   // in pairs: same element offset
+        constexpr int RH = R / 2;
+        // own part into its final register, the partner's part into the register that will receive
+        // the partner's contribution: wave 0 keeps S0, wave 1 keeps S1
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const f4* const p = reinterpret_cast<const f4*>(Sarr + gbase + ((size_t)(64 * j) << cs));
+        for (int jj = 0; jj < RH; ++jj) {
+            const int j = h * RH + jj;                 // slab loaded by this wave (h is wave-uniform)
+            const f4* const p = pairs + ((size_t)(64 * j) << cs);
 #pragma unroll
-        for (int q2 = 0; q2 < M / 2; ++q2) {
-            const f4 v = (p + q2)[loff >> 1];
-            d[(2 * q2) * R + j] = mk<float>(v.x, v.y);
-            d[(2 * q2 + 1) * R + j] = mk<float>(v.z, v.w);
+            for (int q = 0; q < M; ++q) {
+                const f4 v = (p + q)[loff];
+                const cx<float> P = mk<float>(v.x, v.y), Q = mk<float>(v.z, v.w);
+                // registers are indexed statically: jj and jj + RH; which of the two is the own slot depends on h
+                d[q * R + jj] = P;                     // wave 0: own S0 at slab jj; wave 1: S0 of slab jj + RH, for the partner
+                d[q * R + jj + RH] = Q;                // wave 0: S1 of slab jj, for the partner; wave 1: own S1 at slab jj + RH
+            }
+        }
+        // send: wave 0 its S1 values (upper registers), wave 1 its S0 values (lower registers)
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+#pragma unroll
+            for (int jj = 0; jj < RH; ++jj) {
+                const cx<float> lo = d[q * R + jj], hi = d[q * R + jj + RH];
+                mine[(q * RH + jj) * 64 + lane] = h == 0 ? hi : lo;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+#pragma unroll
+            for (int jj = 0; jj < RH; ++jj) {
+                const cx<float> x = theirs[(q * RH + jj) * 64 + lane];
+                const cx<float> lo = d[q * R + jj], hi = d[q * R + jj + RH];
+                // wave 0 receives S0 of slab jj + RH (upper register); wave 1 receives S1 of slab jj (lower register)
+                d[q * R + jj] = h == 0 ? lo : x;
+                d[q * R + jj + RH] = h == 0 ? x : hi;
+            }
+        }
+        __syncthreads();  // both tiles are transposition tiles again
+    } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const f4* const p = reinterpret_cast<const f4*>(Sarr + gbase + ((size_t)(64 * j) << cs));
+#pragma unroll
+            for (int q2 = 0; q2 < M / 2; ++q2) {
+                const f4 v = (p + q2)[loff >> 1];
+                d[(2 * q2) * R + j] = mk<float>(v.x, v.y);
+                d[(2 * q2 + 1) * R + j] = mk<float>(v.z, v.w);
+            }
         }
     }
     pin(d);
@@ -130,7 +179,38 @@ __global__ void __launch_bounds__((MODE == COL_RES2 ? 128 : 64) * NP, 2) k_wave_
     // (after the pair's second barrier each wave touches only its own tile: no barrier needed here)
     wfft::fftN<R, true>(d, a.wtw, mytile, lane);
     pin(d);
-    {
+    if (ILV) {
+        cx<float>* const mine = reinterpret_cast<cx<float>*>(mytile);
+        cx<float>* const theirs = reinterpret_cast<cx<float>*>(tiles + (size_t)(wv ^ NP) * WFFT_TILE_FLOATS);
+        constexpr int RH = R / 2;
+        // wave 0 (holding S0 of every slab) stores the pairs of slabs 0 .. RH - 1 and needs S1 there; it
+        // hands S0 of the upper slabs to wave 1, which stores the pairs of slabs RH .. R - 1
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+#pragma unroll
+            for (int jj = 0; jj < RH; ++jj) {
+                const cx<float> lo = d[q * R + jj], hi = d[q * R + jj + RH];
+                mine[(q * RH + jj) * 64 + lane] = h == 0 ? hi : lo;
+            }
+        }
+        __syncthreads();
+        f4* const pairs = reinterpret_cast<f4*>(a.S0) + opaque(gbase);
+#pragma unroll
+        for (int jj = 0; jj < RH; ++jj) {
+            const int j = h * RH + jj;
+            f4* const p = pairs + ((size_t)(64 * j) << cs);
+#pragma unroll
+            for (int q = 0; q < M; ++q) {
+                const cx<float> x = theirs[(q * RH + jj) * 64 + lane];
+                const cx<float> lo = d[q * R + jj], hi = d[q * R + jj + RH];
+                // wave 0: (own S0 of slab jj, received S1 of slab jj); wave 1: (received S0 of slab jj + RH, own S1)
+                const cx<float> P = h == 0 ? lo : x, Q = h == 0 ? x : hi;
+                f4 v;
+                v.x = P.x; v.y = P.y; v.z = Q.x; v.w = Q.y;
+                (p + q)[loff] = v;
+            }
+        }
+    } else {
         cx<float>* const Sout = Sarr + opaque(gbase);
 #pragma unroll
         for (int j = 0; j < R; ++j) {

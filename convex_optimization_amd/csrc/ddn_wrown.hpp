@@ -36,19 +36,35 @@ struct SpecAddrN {
 };
 
 // Merge: half-spectra A, B (k = 0 .. 32 R) of the two real fields of each row -> spectrum of a + i b.
-template <int R>
+// ILV: the half-spectra are interleaved element by element in one array of 16-byte pairs (see pack).
+template <int R, bool ILV = false>
 __device__ __forceinline__ void packN(cx<float> (&d)[64], const cx<float>* rowA, const cx<float>* rowB, const SpecAddrN<R>& sa, int lane) {
     const int k1 = lane & (R - 1);
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-        d[r] = (rowA + sa.reg(r))[sa.lane_off];       // A[k], k = k1 + R r
-        d[63 - r] = (rowB + sa.reg(r))[sa.lane_off];  // B[k]
-    }
     // column W/2 (real): register 32 of the lanes with k1 = 0; the other lanes would read past the row
     cx<float> Un = mk<float>(0.f, 0.f), Vn = mk<float>(0.f, 0.f);
-    if (k1 == 0) {
-        Un = (rowA + sa.reg(32))[sa.lane_off];
-        Vn = (rowB + sa.reg(32))[sa.lane_off];
+    if (ILV) {
+        const f4* const q = reinterpret_cast<const f4*>(rowA);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const f4 v = (q + sa.reg(r))[sa.lane_off];
+            d[r] = mk<float>(v.x, v.y);
+            d[63 - r] = mk<float>(v.z, v.w);
+        }
+        if (k1 == 0) {
+            const f4 v = (q + sa.reg(32))[sa.lane_off];
+            Un = mk<float>(v.x, v.y);
+            Vn = mk<float>(v.z, v.w);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            d[r] = (rowA + sa.reg(r))[sa.lane_off];       // A[k], k = k1 + R r
+            d[63 - r] = (rowB + sa.reg(r))[sa.lane_off];  // B[k]
+        }
+        if (k1 == 0) {
+            Un = (rowA + sa.reg(32))[sa.lane_off];
+            Vn = (rowB + sa.reg(32))[sa.lane_off];
+        }
     }
     sched_fence();
     const int ml = (lane & ~(R - 1)) | ((R - k1) & (R - 1));
@@ -80,10 +96,11 @@ __device__ __forceinline__ void packN(cx<float> (&d)[64], const cx<float>* rowA,
 }
 
 // Split: spectrum Z of a + i b -> half-spectra of a (to rowA) and b (to rowB).
-template <int R>
+template <int R, bool ILV = false>
 __device__ __forceinline__ void unpackN(const cx<float> (&d)[64], cx<float>* rowA, cx<float>* rowB, const SpecAddrN<R>& sa, int lane) {
     const int k1 = lane & (R - 1);
     const int ml = (lane & ~(R - 1)) | ((R - k1) & (R - 1));
+    f4* const q = reinterpret_cast<f4*>(rowA);
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
         cx<float> Zm = mk<float>(lane_get(d[63 - r].x, ml), lane_get(d[63 - r].y, ml));
@@ -91,17 +108,30 @@ __device__ __forceinline__ void unpackN(const cx<float> (&d)[64], cx<float>* row
         Zm.x = k1 == 0 ? own.x : Zm.x;
         Zm.y = k1 == 0 ? own.y : Zm.y;
         const cx<float> Z = d[r];
-        (rowA + sa.reg(r))[sa.lane_off] = mk<float>(0.5f * (Z.x + Zm.x), 0.5f * (Z.y - Zm.y));
-        (rowB + sa.reg(r))[sa.lane_off] = mk<float>(0.5f * (Z.y + Zm.y), 0.5f * (Zm.x - Z.x));
+        if (ILV) {
+            f4 v;
+            v.x = 0.5f * (Z.x + Zm.x); v.y = 0.5f * (Z.y - Zm.y);
+            v.z = 0.5f * (Z.y + Zm.y); v.w = 0.5f * (Zm.x - Z.x);
+            (q + sa.reg(r))[sa.lane_off] = v;
+        } else {
+            (rowA + sa.reg(r))[sa.lane_off] = mk<float>(0.5f * (Z.x + Zm.x), 0.5f * (Z.y - Zm.y));
+            (rowB + sa.reg(r))[sa.lane_off] = mk<float>(0.5f * (Z.y + Zm.y), 0.5f * (Zm.x - Z.x));
+        }
     }
     if (k1 == 0) {
-        (rowA + sa.reg(32))[sa.lane_off] = mk<float>(d[32].x, 0.f);
-        (rowB + sa.reg(32))[sa.lane_off] = mk<float>(d[32].y, 0.f);
+        if (ILV) {
+            f4 v;
+            v.x = d[32].x; v.y = 0.f; v.z = d[32].y; v.w = 0.f;
+            (q + sa.reg(32))[sa.lane_off] = v;
+        } else {
+            (rowA + sa.reg(32))[sa.lane_off] = mk<float>(d[32].x, 0.f);
+            (rowB + sa.reg(32))[sa.lane_off] = mk<float>(d[32].y, 0.f);
+        }
     }
 }
 
 // PDR / PDDR / ADMM: the policies of ddn_kernels.hpp, one pixel per register (see k_wave_row).
-template <class P, int PD, bool CONS, bool PROD, int FE, int R>
+template <class P, int PD, bool CONS, bool PROD, int FE, int R, bool ILV = false>
 __global__ void __launch_bounds__(64, WROW_MINW) k_wave_rowN(RowCommon<float> c, typename P::Args a0) {
     constexpr int M = 64 / R;
     extern __shared__ __align__(16) float wtiles[];
@@ -116,12 +146,12 @@ __global__ void __launch_bounds__(64, WROW_MINW) k_wave_rowN(RowCommon<float> c,
         typename P::Args a = a0;
         advance(a, opaque((size_t)it * 4096));
         const size_t sbase = opaque(spec_row_base(c.lay, plane, row - plane * c.H));
-        cx<float>* const row0 = c.S0 + sbase;
+        cx<float>* const row0 = c.S0 + (ILV ? 2 : 1) * sbase;  // ILV: S0 holds the (S0, S1) pairs, 16 bytes each
         cx<float>* const row1 = c.S1 + sbase;
         const unsigned ul = (unsigned)lane;
         cx<float> d[64];
         if (CONS) {
-            packN<R>(d, row0, row1, sa, lane);
+            packN<R, ILV>(d, row0, row1, sa, lane);
             wfft::fftN<R, true>(d, c.wtw, tile, lane);
             pin(d);
         } else {
@@ -174,7 +204,7 @@ __global__ void __launch_bounds__(64, WROW_MINW) k_wave_rowN(RowCommon<float> c,
             sched_fence();
             wfft::fftN<R, false>(d, c.wtw, tile, lane);
             pin(d);
-            unpackN<R>(d, row0, row1, sa, lane);
+            unpackN<R, ILV>(d, row0, row1, sa, lane);
         }
     }
 }
@@ -182,6 +212,11 @@ __global__ void __launch_bounds__(64, WROW_MINW) k_wave_rowN(RowCommon<float> c,
 template <class P, int PD, int FE, int R>
 int wrown_go(hipStream_t st, int grid, const RowCommon<float>& c, const typename P::Args& a) {
     const size_t lds = (size_t)WFFT_TILE_FLOATS * sizeof(float);
+    if (c.ilv) {
+        if (c.do_consume && c.do_produce) return launch_row_fn(st, k_wave_rowN<P, PD, true, true, FE, R, true>, grid, 64, lds, c, a);
+        if (c.do_consume) return launch_row_fn(st, k_wave_rowN<P, PD, true, false, 1, R, true>, grid, 64, lds, c, a);
+        return launch_row_fn(st, k_wave_rowN<P, PD, false, true, 1, R, true>, grid, 64, lds, c, a);
+    }
     if (c.do_consume && c.do_produce) return launch_row_fn(st, k_wave_rowN<P, PD, true, true, FE, R>, grid, 64, lds, c, a);
     if (c.do_consume) return launch_row_fn(st, k_wave_rowN<P, PD, true, false, 1, R>, grid, 64, lds, c, a);
     return launch_row_fn(st, k_wave_rowN<P, PD, false, true, 1, R>, grid, 64, lds, c, a);

@@ -24,3 +24,11 @@ for pad in [0, 4096 + 64]:
         torch.add(a[0], a[1], out=a[5])
     t = timeit(g)
     print(f"pad {pad}: add 2r+1w 64MiB arrays: {3*N*4/t/1e12:.2f} TB/s")
+# read-only and write-only streams (is the ceiling a property of reads, of writes, or of the mix?)
+t = timeit(lambda: x.sum())
+print(f"sum (read only) 1 GiB: {x.numel()*4/t/1e12:.2f} TB/s")
+t = timeit(lambda: y.fill_(1.0))
+print(f"fill (write only) 1 GiB: {y.numel()*4/t/1e12:.2f} TB/s")
+h = x.numel() // 2
+t = timeit(lambda: torch.add(x[:h], x[h:], out=y[:h]))
+print(f"add 2r+1w 512 MiB arrays: {3*h*4/t/1e12:.2f} TB/s")

@@ -284,7 +284,12 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
     const int b = blockIdx.x - plane * per_plane;
     int quarter = b;
     if (cs != 2) {
-        const int x = b & 7, aa = b >> 3;
+        // the last group of eight tiles goes first: it holds the lone column W/2, whose workgroup then
+        // runs beside the first round instead of after the second one
+        const int ngrp4 = 4 * ((a.lay.ntile + 7) / 8);
+        const int x = b & 7;
+        int aa = (b >> 3) + ngrp4 - 4;
+        aa = aa >= ngrp4 ? aa - ngrp4 : aa;
         quarter = 4 * (8 * (aa >> 2) + x) + (aa & 3);
     }
     if (a.lf.enabled && quarter == 0) loss_finalize(a.lf, plane, reinterpret_cast<double*>(tiles), tid, NT);

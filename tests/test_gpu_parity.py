@@ -620,3 +620,22 @@ def test_early_stop_on_register_resident_kernels(pkg, golden_dir, H, W):
     xb = pkg.primal_dr_splitting("l1", kern, b2, niters=14, loss_function=pkg.core.mse, tol=tol)
     for i in range(2):
         assert np.array_equal(xb[i].numpy(), singles[i].numpy())
+
+
+def test_config1_256_chambolle_pock_500_iterations(pkg):
+    """The reference's own CPU-sized case: 256 x 256, 9 x 9 Gaussian blur (sigma 0.8), noise std 0.1,
+    Chambolle-Pock with the reference defaults (t = 0.4, s = 0.7: unstable, rounding differences grow).
+    Iterates within 1e-5 of the CPU oracle at N = 20 and N = 100; at N = 500 the iterate within 5e-3
+    (measured 2e-4) and the PSNR against the clean image within 1e-3 dB."""
+    torch.manual_seed(0)
+    img = torch.rand(1, 256, 256)
+    kern = torch.as_tensor(np.asarray(O.gaussian_filter([9, 9], 0.8))).float()
+    b = O.add_gaussian_noise(O.circular_convolve2d(img, kern), 0.0, 0.1)
+    for N, tol in ((20, 1e-5), (100, 1e-5), (500, 5e-3)):
+        torch.manual_seed(7)
+        xo = O.chambolle_pock(b, kern, max_iter=N)
+        torch.manual_seed(7)
+        x = pkg.chambolle_pock_solver(b, kern, max_iter=N)
+        assert x.shape == xo.shape == (1, 256, 256)
+        assert rel(x.numpy(), xo.numpy()) < tol
+        assert abs(float(O.psnr(x, img)) - float(O.psnr(xo, img))) < 1e-3

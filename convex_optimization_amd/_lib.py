@@ -50,6 +50,7 @@ def lib():
         "ddn_prox": [i, i, vp, vp, sz, d, vp],
         "ddn_reduce": [i, vp, vp, sz, i, vp, vp],
         "ddn_ssim": [i, vp, vp, i, i, i, d, C.POINTER(C.c_float), vp, vp],
+        "ddn_apply_x_trans": [i, vp, vp, i, vp, vp],
         "ddn_cp_run": [vp, vp, vp, vp, vp, d, d, d, i, i, vp],
         "ddn_admm_run": [vp, vp, vp, vp, vp, vp, d, d, d, i, i, i, d, i, vp, vp, vp],
         "ddn_pdr_run": [vp, vp, vp, vp, d, d, d, i, i, i, d, i, vp, vp],
@@ -75,5 +76,5 @@ def check(rc: int):
 
 EXPORTED = ["ddn_version", "ddn_last_error", "ddn_plan_create", "ddn_plan_destroy", "ddn_plan_set_stream", "ddn_plan_tune",
             "ddn_plan_set_kernel", "ddn_plan_set_eig", "ddn_plan_set_resolvent", "ddn_plan_get_eigK", "ddn_apply",
-            "ddn_apply_multiplier", "ddn_circular_convolve2d", "ddn_prox", "ddn_reduce", "ddn_ssim", "ddn_cp_run", "ddn_admm_run",
+            "ddn_apply_multiplier", "ddn_circular_convolve2d", "ddn_prox", "ddn_reduce", "ddn_ssim", "ddn_apply_x_trans", "ddn_cp_run", "ddn_admm_run",
             "ddn_pdr_run", "ddn_pddr_run", "ddn_plan_last_timing", "ddn_plan_enable_timing", "ddn_plan_debug_stamps"]

@@ -123,7 +123,42 @@ __global__ void k_ssim_final(const double* partial, int per_plane, double npix, 
     if (tid == 0) out[plane] = red[0] / npix;
 }
 
+// X^T w for the k x k blind-kernel step (op_math/python_code/apply_x_trans.py:4-46), k odd:
+// out[i][j] = sum_{p,q} w[p][q] x[p + i - k/2][q + j - k/2], x zero outside (the reference correlates x
+// with a one-hot kernel at (i, j) under zero padding k/2 and sums the product with w).  One thread
+// per output entry, double accumulation.
+template <typename T>
+__global__ void k_apply_x_trans(const T* __restrict__ w, const T* __restrict__ x, int k, T* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= k * k) return;
+    const int i = idx / k, j = idx - i * k, c = k / 2;
+    double acc = 0.0;
+    for (int p = 0; p < k; ++p) {
+        const int xr = p + i - c;
+        if (xr < 0 || xr >= k) continue;
+        for (int q = 0; q < k; ++q) {
+            const int xc = q + j - c;
+            if (xc < 0 || xc >= k) continue;
+            acc += (double)w[p * k + q] * (double)x[xr * k + xc];
+        }
+    }
+    out[idx] = (T)acc;
+}
+
 }  // namespace
+
+extern "C" int ddn_apply_x_trans(int dtype, const void* w_dev, const void* x_dev, int kernel_size, void* out_dev, void* stream) {
+    if (!w_dev || !x_dev || !out_dev || kernel_size < 1) return fail(DDN_E_ARG, "apply_x_trans: bad arguments");
+    if (kernel_size % 2 == 0) return fail(DDN_E_UNSUPPORTED, "apply_x_trans: kernel_size must be odd (the reference's padded correlation is (k+1) x (k+1) for even k and cannot be multiplied with w)");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = kernel_size * kernel_size;
+    if (dtype == DDN_F32)
+        hipLaunchKernelGGL(k_apply_x_trans<float>, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)w_dev, (const float*)x_dev, kernel_size, (float*)out_dev);
+    else
+        hipLaunchKernelGGL(k_apply_x_trans<double>, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)w_dev, (const double*)x_dev, kernel_size, (double*)out_dev);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
 
 extern "C" int ddn_ssim(int dtype, const void* x, const void* y, int H, int W, int planes, double max_val, const float* g11_host, double* out_dev, void* stream) {
     if (!x || !y || !out_dev || !g11_host || H < 1 || W < 1 || planes < 1) return fail(DDN_E_ARG, "ssim: bad arguments");

@@ -132,6 +132,12 @@ int ddn_reduce(int dtype, const void* x_dev, const void* y_dev, size_t n_per_ima
  * Synchronises the stream.  (A [B,C,H,W] input is B*C planes; the caller averages over C.) */
 int ddn_ssim(int dtype, const void* x_dev, const void* y_dev, int H, int W, int planes, double max_val, const float* g11_host, double* out_dev, void* stream);
 
+/* X^T w of the blind-kernel step (op_math/python_code/apply_x_trans.py:4-46): w, x, out are
+ * kernel_size x kernel_size arrays; out[i][j] = <w, x correlated with a one-hot kernel at (i, j) under
+ * zero padding kernel_size / 2>.  kernel_size must be odd: for even sizes the reference's padded
+ * correlation has kernel_size + 1 rows and its product with w raises. */
+int ddn_apply_x_trans(int dtype, const void* w_dev, const void* x_dev, int kernel_size, void* out_dev, void* stream);
+
 /* ---- solver loops -------------------------------------------------------------
  * Each *_run advances the iterate arrays in place by up to n_iters iterations of the
  * reference loop body.  Per iteration the device records, per image, the four loss

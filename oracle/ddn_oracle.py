@@ -351,6 +351,21 @@ def primal_dual_dr_splitting(b, kernel, niters=1000, t=3, rho=0.4, gamma=0.03, l
 
 
 # --------------------------------------------------------- fused real-FFT restatement
+def apply_x_trans(w, x, kernel_size):
+    """deblur_denoise/op_math/python_code/apply_x_trans.py:4-46: entry (i, j) is the sum of w times x
+    correlated with a one-hot kernel at (i, j) under zero padding kernel_size // 2 (axt:29-44)."""
+    import torch.nn.functional as F
+    k = kernel_size
+    xtw = torch.zeros((k, k))                                                          # axt:26-27
+    for i in range(k):
+        for j in range(k):
+            shift = torch.zeros((k, k))
+            shift[i, j] = 1                                                            # axt:31-32
+            conv = F.conv2d(x[None, None], shift[None, None], padding=(k // 2, k // 2)).squeeze()   # axt:36-41
+            xtw[i, j] = torch.sum(w * conv)                                            # axt:44
+    return xtw
+
+
 def herm_half(e: np.ndarray) -> np.ndarray:
     """Hermitian-symmetrise a full H x W multiplier and keep columns 0..W/2:
     e_h[k] = (e[k] + conj(e[-k]))/2 -- what `.real` after ifft2 does implicitly."""

@@ -84,6 +84,7 @@ class LossRecorder:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default="", help="write only this fixture file (e.g. xtrans) and leave the others untouched")
     args = ap.parse_args()
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
@@ -100,6 +101,19 @@ def main():
     from deblur_denoise.admm import algorithm as admm_mod
     from deblur_denoise.primal_dr import algorithm as pdr_mod
     from deblur_denoise.primal_dual_dr import algorithm as pddr_mod
+
+    if args.only == "xtrans":
+        # ---------------------------------------------------------------- apply_x_trans
+        from deblur_denoise.op_math.python_code.apply_x_trans import apply_x_trans
+        xt = {}
+        for k in (3, 5, 9, 15):
+            torch.manual_seed(40 + k)
+            w, x = torch.rand(k, k), torch.rand(k, k)
+            xt[f"w{k}"], xt[f"x{k}"] = to_np(w), to_np(x)
+            xt[f"out{k}"] = to_np(apply_x_trans(w, x, k))
+        np.savez_compressed(os.path.join(out, "xtrans.npz"), **xt)
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
 
     # ------------------------------------------------------------------ kernels
     kernels = {

@@ -639,3 +639,23 @@ def test_config1_256_chambolle_pock_500_iterations(pkg):
         assert x.shape == xo.shape == (1, 256, 256)
         assert rel(x.numpy(), xo.numpy()) < tol
         assert abs(float(O.psnr(x, img)) - float(O.psnr(xo, img))) < 1e-3
+
+
+def test_apply_x_trans_vs_reference_golden(pkg, golden_dir):
+    """op_math/python_code/apply_x_trans.py:4-46 on the device against the reference's own outputs
+    (float32, rel-L2 <= 1e-6: the device accumulates in double) and the oracle; float64 inputs against a
+    float64 evaluation of the same sums; even sizes raise as the reference does."""
+    g = _load(golden_dir, "xtrans.npz")
+    for k in (3, 5, 9, 15):
+        w, x = torch.from_numpy(g[f"w{k}"]), torch.from_numpy(g[f"x{k}"])
+        out = pkg.op_math.apply_x_trans(w, x, k)
+        assert out.shape == (k, k) and out.dtype == torch.float32 and out.device == w.device
+        assert rel(out.numpy(), g[f"out{k}"]) < 1e-6
+        assert rel(out.numpy(), O.apply_x_trans(w, x, k).numpy()) < 1e-6
+        outd = pkg.op_math.apply_x_trans(w.double().cuda(), x.double().cuda(), k, dtype=torch.float64)
+        c = k // 2
+        xp = torch.nn.functional.pad(x.double(), (c, c, c, c))
+        exp = torch.stack([torch.stack([(w.double() * xp[i:i + k, j:j + k]).sum() for j in range(k)]) for i in range(k)])
+        assert outd.is_cuda and rel(outd.cpu().numpy(), exp.numpy()) < 1e-14
+    with pytest.raises(RuntimeError):
+        pkg.op_math.apply_x_trans(torch.rand(4, 4), torch.rand(4, 4), 4)

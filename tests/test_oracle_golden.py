@@ -205,3 +205,11 @@ def test_fused_restatement_matches_reference(golden_dir, dtn, kname):
         assert O.rel_l2(x, g[f"cpstab_l1_N{N}"][0]) < tol
     x = O.fused_cp(fo1, b, g["cp_x0"], g["cp_z0"], g["cp_y0"], "l1", 21, 0.4, 0.7, 0.01, sd)
     assert O.rel_l2(x, g["cpdef_l1_N20"][0]) < tol
+
+
+def test_apply_x_trans(golden_dir):
+    """op_math/python_code/apply_x_trans.py: the restatement reproduces the reference's outputs bit for bit."""
+    g = _load(golden_dir, "xtrans.npz")
+    for k in (3, 5, 9, 15):
+        out = O.apply_x_trans(torch.from_numpy(g[f"w{k}"]), torch.from_numpy(g[f"x{k}"]), k)
+        assert np.array_equal(out.numpy(), g[f"out{k}"])

@@ -56,6 +56,10 @@ def lib():
         "ddn_pdr_run": [vp, vp, vp, vp, d, d, d, i, i, i, d, i, vp, vp],
         "ddn_pddr_run": [vp, vp, vp, vp, d, d, d, i, i, d, i, vp, vp],
         "ddn_plan_enable_timing": [vp, i],
+        "ddn_slab_layout": [vp, C.POINTER(i), C.POINTER(i)],
+        "ddn_slab_rows": [vp, i, i, vp, vp, vp, vp, vp, vp, d, d, d, i, i, i, vp, i],
+        "ddn_slab_cols": [vp, vp, i, i],
+        "ddn_slab_loss": [vp, i, vp],
         "ddn_plan_last_timing": [vp, C.POINTER(d), C.POINTER(d), C.POINTER(i), C.POINTER(i)],
     }
     for name, args in sigs.items():
@@ -77,4 +81,5 @@ def check(rc: int):
 EXPORTED = ["ddn_version", "ddn_last_error", "ddn_plan_create", "ddn_plan_destroy", "ddn_plan_set_stream", "ddn_plan_tune",
             "ddn_plan_set_kernel", "ddn_plan_set_eig", "ddn_plan_set_resolvent", "ddn_plan_get_eigK", "ddn_apply",
             "ddn_apply_multiplier", "ddn_circular_convolve2d", "ddn_prox", "ddn_reduce", "ddn_ssim", "ddn_apply_x_trans", "ddn_cp_run", "ddn_admm_run",
-            "ddn_pdr_run", "ddn_pddr_run", "ddn_plan_last_timing", "ddn_plan_enable_timing", "ddn_plan_debug_stamps"]
+            "ddn_pdr_run", "ddn_pddr_run", "ddn_plan_last_timing", "ddn_plan_enable_timing", "ddn_plan_debug_stamps",
+            "ddn_slab_layout", "ddn_slab_rows", "ddn_slab_cols", "ddn_slab_loss"]

@@ -175,6 +175,7 @@ struct ddn_plan {
     double* partials = nullptr;  // [batch*H][4]
     int* stop = nullptr;         // [batch]
     bool have_K = false, have_G = false, injected = false;
+    bool slab_cols = false;      // a column stage over a tile range of a row-slab decomposition: tile-generic kernels only
     long long* dbg = nullptr;    // diagnostic phase stamps (DDN_DEBUG_STAMPS=1), 16 per workgroup
     // timing
     bool timing = false;
@@ -404,11 +405,11 @@ inline int col_threads_for(const ddn_plan* p, int n, int cs, int narr) {
 inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
 
 inline bool wcol_ready(const ddn_plan* p) {
-    return p->eKc_ok && p->wtw && p->H == 4096 && (p->cs == 4 || p->cs == 2) && !p->injected && !getenv("DDN_NO_WAVE_COLS");
+    return p->eKc_ok && p->wtw && p->H == 4096 && (p->cs == 4 || p->cs == 2) && !p->injected && !p->slab_cols && !getenv("DDN_NO_WAVE_COLS");
 }
 // H = 512 / 1024 / 2048: several adjacent columns per wavefront (ddn_wcoln.hpp)
 inline bool wcoln_ready(const ddn_plan* p) {
-    return p->eKc_ok && p->wtwH && (1 << p->cs) >= 4096 / p->H && p->cs <= 4 && !p->injected && !getenv("DDN_NO_WAVE_COLS");
+    return p->eKc_ok && p->wtwH && (1 << p->cs) >= 4096 / p->H && p->cs <= 4 && !p->injected && !p->slab_cols && !getenv("DDN_NO_WAVE_COLS");
 }
 // column-major natural-order copy of a tiled multiplier (complex and / or real)
 template <typename T>
@@ -954,6 +955,91 @@ int apply_impl(ddn_plan* p, int op, const void* x, void* y) {
     return fail(DDN_E_ARG, "apply: unknown operator");
 }
 
+// ------------------------------------------------ one image split into row slabs over several GPUs
+// The plan is created with the full image size (its multipliers cover every frequency); a rank owns
+// `rows` consecutive image rows and a range of spectral tiles.  The fused row kernels run on the
+// local rows with a caller-owned half-spectrum buffer laid out [tile][2 spectra][rows][C], so that
+// the tiles of one destination rank are one contiguous block of it; the column stage runs on the
+// local tile range of a caller-owned [2 spectra][local tiles][H][C] buffer.  The exchange between
+// the two buffers (an all-to-all) belongs to the caller.
+struct SlabRows {
+    ddn_plan* p;
+    int H;
+    SlabRows(ddn_plan* q, int rows) : p(q), H(q->H) { p->H = rows; }
+    ~SlabRows() { p->H = H; }
+};
+
+template <typename T>
+int slab_rows_impl(ddn_plan* p, int solver, int rows, void* spec, void* s0, void* s1, void* s2, void* s3, const void* b,
+                   double t, double rho, double gamma, int objective, int consume, int produce, void* sol, int sol_only) {
+    if (!p->have_K || !p->have_G) return fail(DDN_E_STATE, "slab_rows: operators not set");
+    if (p->injected) return fail(DDN_E_UNSUPPORTED, "slab_rows: injected eigen arrays are not supported");
+    SlabRows guard(p, rows);  // row_cfg / row_common size the launch from p->H
+    const size_t plane = (size_t)rows * p->W;
+    RowCfg cfg;
+    const bool al = aligned16(s0) && aligned16(s1) && (!s2 || aligned16(s2)) && (!s3 || aligned16(s3)) && aligned16(b) && (!sol || aligned16(sol)) &&
+                    ((plane * sizeof(T)) % 16 == 0);
+    if (!row_cfg<T>(p, al, rows, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    int rc;
+    if ((rc = reset_stop<T>(p))) return rc;
+    RowCommon<T> c = row_common<T>(p, cfg.V, consume != 0, produce != 0);
+    const size_t C = (size_t)1 << p->cs;
+    c.S0 = (cx<T>*)spec;
+    c.S1 = (cx<T>*)spec + (size_t)rows * C;
+    c.lay.H = 2 * rows;  // tile pitch in rows: S0 rows then S1 rows of a tile
+    c.nyqd = nullptr;
+    c.ilv = 0;
+    if (solver == 0) {
+        typename AdmmP<T>::Args a;
+        std::memset(&a, 0, sizeof(a));
+        a.u = (T*)s0; a.w = (T*)s1;
+        a.y0 = (T*)s2; a.y1 = (T*)s2 + plane; a.y2 = (T*)s2 + 2 * plane;
+        a.z0 = (T*)s3; a.z1 = (T*)s3 + plane; a.z2 = (T*)s3 + 2 * plane;
+        a.b = (const T*)b;
+        a.t = (T)t; a.it = (T)(1.0 / t); a.rho = (T)rho; a.omr = (T)(1.0 - rho); a.itg = (T)((1.0 / t) * gamma);
+        a.l2div = (T)(2 * (1.0 / t) + 1); a.objective = objective;
+        a.sol = (T*)sol; a.sol_only = sol_only;
+        if (!s2 || !s3) return fail(DDN_E_ARG, "slab_rows: admm needs u, w, y, z");
+        return launch_solver_row<T, AdmmP<T>>(p, cfg, c, a);
+    }
+    if (solver == 1) {
+        typename PdrP<T>::Args a;
+        std::memset(&a, 0, sizeof(a));
+        a.z1 = (T*)s0; a.z20 = (T*)s1; a.z21 = (T*)s1 + plane; a.z22 = (T*)s1 + 2 * plane; a.b = (const T*)b;
+        a.t = (T)t; a.rho = (T)rho; a.tg = (T)(t * gamma); a.l2div = (T)(2 * t + 1); a.objective = objective;
+        return launch_solver_row<T, PdrP<T>>(p, cfg, c, a);
+    }
+    if (solver == 2) {
+        typename PddrP<T>::Args a;
+        std::memset(&a, 0, sizeof(a));
+        a.p = (T*)s0; a.q0 = (T*)s1; a.q1 = (T*)s1 + plane; a.q2 = (T*)s1 + 2 * plane; a.b = (const T*)b;
+        a.t = (T)t; a.it = (T)(1.0 / t); a.rho = (T)rho; a.itg = (T)((1.0 / t) * gamma);
+        return launch_solver_row<T, PddrP<T>>(p, cfg, c, a);
+    }
+    return fail(DDN_E_ARG, "slab_rows: unknown solver");
+}
+
+// Column stage of the resolvent solvers on tiles [tile_lo, tile_lo + ntiles) of the image's half-spectra.
+template <typename T>
+int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles) {
+    if (!p->have_K || !p->have_G) return fail(DDN_E_STATE, "slab_cols: operators not set");
+    if (p->injected) return fail(DDN_E_UNSUPPORTED, "slab_cols: injected eigen arrays are not supported");
+    if (ntiles == 0) return DDN_OK;
+    // the plan's own fields are pointed at the local tile range for the duration of the call; the
+    // multipliers are offset to the same tiles, which also selects the tile-generic column kernels
+    struct Swap {
+        ddn_plan* p; void* S0; void* S1; int ntile;
+        explicit Swap(ddn_plan* q) : p(q), S0(q->S0), S1(q->S1), ntile(q->ntile) { p->slab_cols = true; }
+        ~Swap() { p->S0 = S0; p->S1 = S1; p->ntile = ntile; p->slab_cols = false; }
+    } guard(p);
+    const size_t tile_elems = ((size_t)(p->H + p->tile_pad_rows)) << p->cs;
+    p->S0 = spec;
+    p->S1 = (cx<T>*)spec + (size_t)ntiles * tile_elems;
+    p->ntile = ntiles;
+    const size_t off = (size_t)tile_lo * tile_elems;
+    return col_stage<T, COL_RES2>(p, 1, (const cx<T>*)p->eK + off, (const T*)p->G + off, nullptr, 0, (T)1, no_loss());
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
@@ -1213,6 +1299,48 @@ int ddn_pddr_run(ddn_plan* p, void* pp, void* q, const void* b, double t, double
 }
 
 // diagnostic: copies the phase stamps of the last fused row kernel launch (16 int64 per workgroup)
+int ddn_slab_layout(ddn_plan* p, int* tile_cols, int* n_tiles) {
+    if (!p) return fail(DDN_E_ARG, "slab_layout: null plan");
+    if (tile_cols) *tile_cols = 1 << p->cs;
+    if (n_tiles) *n_tiles = p->ntile;
+    return DDN_OK;
+}
+
+int ddn_slab_rows(ddn_plan* p, int solver, int rows, void* spec_rows, void* s0, void* s1, void* s2, void* s3, const void* b,
+                  double t, double rho, double gamma, int objective, int consume, int produce, void* sol, int sol_only) {
+    if (!p || !spec_rows || !s0 || !s1 || !b) return fail(DDN_E_ARG, "slab_rows: null argument");
+    if (p->batch != 1) return fail(DDN_E_ARG, "slab_rows: the plan must hold one image");
+    if (rows < 1 || rows > p->H) return fail(DDN_E_ARG, "slab_rows: bad row count");
+    if (p->tile_pad_rows) return fail(DDN_E_UNSUPPORTED, "slab_rows: padded tiles are not supported");
+    if (p->dtype == DDN_F32) return slab_rows_impl<float>(p, solver, rows, spec_rows, s0, s1, s2, s3, b, t, rho, gamma, objective, consume, produce, sol, sol_only);
+    return slab_rows_impl<double>(p, solver, rows, spec_rows, s0, s1, s2, s3, b, t, rho, gamma, objective, consume, produce, sol, sol_only);
+}
+
+int ddn_slab_cols(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local) {
+    if (!p || (!spec_cols && n_tiles_local > 0)) return fail(DDN_E_ARG, "slab_cols: null argument");
+    if (p->batch != 1) return fail(DDN_E_ARG, "slab_cols: the plan must hold one image");
+    if (tile_lo < 0 || n_tiles_local < 0 || tile_lo + n_tiles_local > p->ntile) return fail(DDN_E_ARG, "slab_cols: bad tile range");
+    if (p->tile_pad_rows) return fail(DDN_E_UNSUPPORTED, "slab_cols: padded tiles are not supported");
+    if (p->dtype == DDN_F32) return slab_cols_impl<float>(p, spec_cols, tile_lo, n_tiles_local);
+    return slab_cols_impl<double>(p, spec_cols, tile_lo, n_tiles_local);
+}
+
+int ddn_slab_loss(ddn_plan* p, int rows, double* record8) {
+    if (!p || !record8) return fail(DDN_E_ARG, "slab_loss: null argument");
+    if (p->batch != 1 || rows < 1 || rows > p->H) return fail(DDN_E_ARG, "slab_loss: bad arguments");
+    LossFin lf;
+    std::memset(&lf, 0, sizeof(lf));
+    lf.partials = p->partials;
+    lf.ring = record8;
+    lf.rows_per_plane = rows;
+    lf.iter = 1; lf.first_iter = 1;
+    lf.npix = (double)p->H * (double)p->W;
+    lf.enabled = 1;
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, p->stream, lf);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
 int ddn_plan_debug_stamps(ddn_plan* p, long long* out_host, int n_wg) {
     if (!p || !p->dbg) return fail(DDN_E_STATE, "debug stamps are off (set DDN_DEBUG_STAMPS=1 before plan_create)");
     HIPCHK(hipStreamSynchronize(p->stream));

@@ -1,0 +1,300 @@
+"""One image split into row slabs over the GPUs of a node.
+
+The reference transforms a whole image per call (apply_periodic_conv_2d.py:3-28: fft2, multiply,
+ifft2); an image too large for one GPU, or one that should be solved faster than one GPU can, is
+split here by rows.  Rank r owns H / P consecutive image rows of every iterate array.  Everything
+the solver loops do per pixel — the row transforms, D and its adjoint (a horizontal difference,
+multiplying_matrix.py:55-59), the prox maps, the relaxation and dual updates, the loss sums — is
+local to a row and runs in the fused row kernel on the slab.  Only the column stage (column
+transform, resolvent algebra, inverse column transform) needs whole columns: before it the
+half-spectra are redistributed so that every rank holds all H rows of its share of the spectral
+tiles, and afterwards back.  Both redistributions are one all-to-all each (RCCL over xGMI with the
+"nccl" backend; CPU tensors with "gloo" in tests).
+
+Layouts (C = columns per spectral tile, complex elements):
+  row side     [n_tiles][2][rows][C]          the tiles that go to one rank are contiguous
+  column side  [2][local tiles][H][C]         what the column kernel streams
+The all-to-all delivers [source rank][local tiles][2][rows][C]; one strided device copy turns that
+into the column-side layout (and back).
+
+Loss records add up over ranks: every rank finalises the sums of its own rows, the sums of |d| and
+d^2 are all-reduced once per solve, and l2 / mse / psnr are recomputed from the totals.  There is
+no early stop in the slab loops (the reference's `break` needs the global loss every iteration).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .distributed import shard_range
+
+SOLVER_ADMM, SOLVER_PDR, SOLVER_PDDR = 0, 1, 2
+
+
+class SlabLayout:
+    """Who owns what: `rows` image rows per rank and a contiguous span of spectral tiles per rank."""
+
+    def __init__(self, H: int, W: int, tile_cols: int, n_tiles: int, rank: int, world: int):
+        if H % world:
+            raise ValueError(f"image height {H} is not a multiple of the number of ranks {world}")
+        self.H, self.W, self.C, self.n_tiles, self.rank, self.world = int(H), int(W), int(tile_cols), int(n_tiles), int(rank), int(world)
+        self.rows = H // world
+        self.row_lo = rank * self.rows
+        self.tile_spans: List[Tuple[int, int]] = [shard_range(n_tiles, r, world) for r in range(world)]
+        self.tile_lo, self.tile_hi = self.tile_spans[rank]
+        self.local_tiles = self.tile_hi - self.tile_lo
+
+
+def _world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+class SlabExchange:
+    """The two spectral buffers of a rank and the all-to-all transposes between them."""
+
+    def __init__(self, lay: SlabLayout, complex_dtype: torch.dtype, device, group=None):
+        self.lay, self.group = lay, group
+        self.spec_rows = torch.zeros((lay.n_tiles, 2, lay.rows, lay.C), dtype=complex_dtype, device=device)
+        self.spec_cols = torch.zeros((2, lay.local_tiles, lay.H, lay.C), dtype=complex_dtype, device=device)
+        self._stage = torch.zeros((lay.world, lay.local_tiles, 2, lay.rows, lay.C), dtype=complex_dtype, device=device)
+        per_tile = 2 * lay.rows * lay.C * 2  # real numbers per tile of the row-side layout
+        self._row_splits = [(hi - lo) * per_tile for lo, hi in lay.tile_spans]
+        self._col_splits = [lay.local_tiles * per_tile] * lay.world
+
+    def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], in_splits: Sequence[int]):
+        o = torch.view_as_real(out).reshape(-1)
+        i = torch.view_as_real(inp).reshape(-1)
+        if self.lay.world == 1:
+            o.copy_(i)
+            return
+        if dist.get_backend(self.group) == "gloo" and o.is_cuda:
+            # gloo has no device all-to-all: stage through host memory (tests on a single GPU only)
+            oc, ic = torch.empty(o.shape, dtype=o.dtype), i.cpu()
+            dist.all_to_all_single(oc, ic, list(out_splits), list(in_splits), group=self.group)
+            o.copy_(oc)
+            return
+        dist.all_to_all_single(o, i, list(out_splits), list(in_splits), group=self.group)
+
+    def _cols_view(self) -> torch.Tensor:
+        l = self.lay  # [2][tiles][H][C] seen as [2][tiles][source rank][rows][C]
+        return self.spec_cols.view(2, l.local_tiles, l.world, l.rows, l.C)
+
+    def rows_to_cols(self):
+        """Every rank's rows of my tiles -> spec_cols (all H rows of the local tiles)."""
+        self._a2a(self._stage, self.spec_rows, self._col_splits, self._row_splits)
+        self._cols_view().copy_(self._stage.permute(2, 1, 0, 3, 4))
+
+    def cols_to_rows(self):
+        """spec_cols -> my rows of every tile in spec_rows."""
+        self._stage.copy_(self._cols_view().permute(2, 1, 0, 3, 4))
+        self._a2a(self.spec_rows, self._stage, self._row_splits, self._col_splits)
+
+
+def combine_loss_records(local: torch.Tensor, npix: float, group=None) -> torch.Tensor:
+    """local: [iters][8] per-slab records (l1, l2, mse, psnr of two pairs).  Returns the records of the
+    whole image: l1 and l2^2 are sums over the slabs; mse and psnr follow from the totals."""
+    sums = torch.stack((local[:, 0], local[:, 1] ** 2, local[:, 4], local[:, 5] ** 2), dim=1).contiguous()
+    _, world = _world(group)
+    if world > 1:
+        if dist.get_backend(group) == "gloo" and sums.is_cuda:
+            h = sums.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            sums = h.to(local.device)
+        else:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    out = torch.empty_like(local)
+    for pair in range(2):
+        s1, s2 = sums[:, 2 * pair], sums[:, 2 * pair + 1]
+        mse = s2 / npix
+        out[:, 4 * pair + 0] = s1
+        out[:, 4 * pair + 1] = torch.sqrt(s2)
+        out[:, 4 * pair + 2] = mse
+        out[:, 4 * pair + 3] = torch.where(mse == 0, torch.full_like(mse, math.inf), 10.0 * torch.log10(1.0 / mse))
+    return out
+
+
+class SlabSolver:
+    """Plan, buffers and the two local stages of one slab-decomposed solve (fp32 or fp64)."""
+
+    def __init__(self, kernel, image_shape: Tuple[int, int], t_resolvent: float, s_resolvent: float, dtype=torch.float32, device=None, group=None):
+        from . import _lib as L
+        from .plan import Plan, compute_device, real_dtype
+        self.L = L
+        self.group = group
+        self.rank, self.world = _world(group)
+        H, W = int(image_shape[0]), int(image_shape[1])
+        self.dt = real_dtype(dtype)
+        self.dev = compute_device(device)
+        self.plan = Plan(H, W, 1, self.dt, self.dev)
+        self.plan.set_kernel(kernel)
+        # eig_vals_mat = 1 + t^2 |eK|^2 + (t^2 + t s) |eD|^2   (multiplying_matrix.py:61-72 with D1 == D2)
+        self.plan.set_resolvent(float(t_resolvent) ** 2, float(t_resolvent) ** 2 + float(t_resolvent) * float(s_resolvent))
+        c, n = C.c_int(0), C.c_int(0)
+        L.check(L.lib().ddn_slab_layout(self.plan._h, C.byref(c), C.byref(n)))
+        self.lay = SlabLayout(H, W, c.value, n.value, self.rank, self.world)
+        self.xch = SlabExchange(self.lay, torch.complex128 if self.dt == torch.float64 else torch.complex64, self.dev, group)
+        self._rec = torch.zeros((8,), dtype=torch.float64, device=self.dev)
+
+    def close(self):
+        self.plan.close()
+
+    def rows(self, solver: int, state: Sequence[Optional[torch.Tensor]], b: torch.Tensor, t: float, rho: float, gamma: float, objective: int,
+             consume: bool, produce: bool, sol: Optional[torch.Tensor] = None, sol_only: bool = False):
+        from .plan import _ptr
+        s = list(state) + [None] * (4 - len(state))
+        self.L.check(self.L.lib().ddn_slab_rows(self.plan._h, solver, self.lay.rows, _ptr(self.xch.spec_rows), _ptr(s[0]), _ptr(s[1]), _ptr(s[2]), _ptr(s[3]),
+                                                _ptr(b), float(t), float(rho), float(gamma), int(objective), int(consume), int(produce), _ptr(sol), int(sol_only)))
+
+    def column_stage(self):
+        """rows -> columns all-to-all, local column stage, columns -> rows all-to-all."""
+        from .plan import _ptr
+        self.xch.rows_to_cols()
+        self.L.check(self.L.lib().ddn_slab_cols(self.plan._h, _ptr(self.xch.spec_cols), self.lay.tile_lo, self.lay.local_tiles))
+        self.xch.cols_to_rows()
+
+    def loss_record(self, out: torch.Tensor):
+        """out[8] <- the loss sums of the local rows seen by the last consuming row launch."""
+        from .plan import _ptr
+        self.L.check(self.L.lib().ddn_slab_loss(self.plan._h, self.lay.rows, _ptr(out)))
+
+
+def _local_rows(full: torch.Tensor, lay: SlabLayout) -> torch.Tensor:
+    return full[..., lay.row_lo:lay.row_lo + lay.rows, :]
+
+
+def admm_solver_slab(b_rows: torch.Tensor, image_shape: Tuple[int, int], objective_function: str = "l1", t: float = 18, rho: float = 0.001,
+                     gamma: float = 0.5, kernel=None, niters: int = 500, **kwargs):
+    """admm_solver (admm/algorithm.py:20-201) for one image whose rows are spread over the ranks of
+    `group`.  b_rows: this rank's (H / P, W) rows of the blurred image.  Returns this rank's rows of the
+    solution of the final solve (admm:160-173).  Runs niters - 1 iterations; no early stop.
+
+    Keyword extensions: init_state = (u, w, y, z) local slabs ((rows, W) and (3, rows, W)); without it
+    the reference's draws (admm:49-54) are made for the WHOLE image on every rank from torch's CPU
+    generator and the local rows kept, so that all ranks must share the generator state;
+    return_state, return_losses (records of the whole image: list of dicts l1_loss, l2_loss, mse,
+    psnr per recorded iteration), dtype, device, group."""
+    if objective_function not in ("l1", "l2"):
+        raise ValueError("Invalid objective function. Choose 'l1' or 'l2'.")
+    from . import _lib as L
+    from .plan import stage
+    H, W = int(image_shape[0]), int(image_shape[1])
+    sv = SlabSolver(kernel, (H, W), 1, 1, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"))
+    try:
+        lay, dev, dt = sv.lay, sv.dev, sv.dt
+        if tuple(b_rows.shape) != (lay.rows, W):
+            raise ValueError(f"b_rows must hold this rank's {lay.rows} x {W} rows, got {tuple(b_rows.shape)}")
+        init = kwargs.get("init_state")
+        if init is None:
+            _x = torch.clamp(torch.randn((H, W), dtype=torch.float32), min=0, max=1)
+            full = [torch.clamp(torch.randn(shape, dtype=torch.float32), min=0, max=1) for shape in ((H, W), (H, W), (3, H, W), (3, H, W))]
+            init = [_local_rows(v, lay) for v in full]
+        u, w, y, z = [stage(torch.as_tensor(v), dev, dt) for v in init]
+        bd = stage(b_rows, dev, dt)
+        sol = torch.zeros_like(bd)
+        n = max(int(niters) - 1, 0)
+        obj = L.OBJ[objective_function]
+        ring = torch.zeros((max(n, 1), 8), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            sv.plan.sync_stream()
+            st = (u, w, y, z)
+            sv.rows(SOLVER_ADMM, st, bd, t, rho, gamma, obj, False, True)
+            for c in range(1, n + 1):
+                sv.column_stage()
+                sv.rows(SOLVER_ADMM, st, bd, t, rho, gamma, obj, True, True)
+                if c >= 2:
+                    sv.loss_record(ring[c - 2])   # the look-ahead solution of iteration c - 1 (admm:118-139)
+            sv.column_stage()
+            sv.rows(SOLVER_ADMM, st, bd, t, rho, gamma, obj, True, False, sol=sol, sol_only=True)
+            if n >= 1:
+                sv.loss_record(ring[n - 1])
+            torch.cuda.synchronize(dev)
+        ret = [sol.to(b_rows.device)]
+        if kwargs.get("return_state"):
+            ret.append(tuple(v.to(b_rows.device) for v in st))
+        if kwargs.get("return_losses"):
+            ret.append(combine_loss_records(ring[:n], float(H) * float(W), kwargs.get("group")).cpu())
+        return ret[0] if len(ret) == 1 else tuple(ret)
+    finally:
+        sv.close()
+
+
+def _dr_slab(solver: int, n: int, sv: SlabSolver, st, bd, t, rho, gamma, obj, ring):
+    sv.rows(solver, st, bd, t, rho, gamma, obj, False, True)
+    for c in range(1, n + 1):
+        sv.column_stage()
+        sv.rows(solver, st, bd, t, rho, gamma, obj, True, c < n)
+        sv.loss_record(ring[c - 1])
+
+
+def primal_dr_splitting_slab(problem: str, kernel, b_rows: torch.Tensor, image_shape: Tuple[int, int], niters: int = 500, gamma: float = 0.049,
+                             t: float = 2.0, rho: float = 0.1, **kwargs):
+    """primal_dr_splitting (primal_dr/algorithm.py:21-187) on row slabs: niters iterations from
+    z1 = b, z2 = (b, b, b) (pdr:88-89) unless init_state = (z1, z2) local slabs is given; problem 'l1'
+    selects the l1 data term, anything else the squared-l2 one (pdr:101-110).  Returns this rank's rows
+    of clip(z1) (pdr:182-187).  Loss records: primary pair (z1, z1prev), secondary (z1, b)."""
+    from .plan import stage
+    from .core.proximal_operators import prox_box
+    H, W = int(image_shape[0]), int(image_shape[1])
+    sv = SlabSolver(kernel, (H, W), t, t, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"))
+    try:
+        dev, dt = sv.dev, sv.dt
+        bd = stage(b_rows, dev, dt)
+        init = kwargs.get("init_state")
+        if init is None:
+            z1, z2 = bd.clone(), torch.stack((bd, bd, bd)).contiguous()
+        else:
+            z1, z2 = [stage(torch.as_tensor(v), dev, dt) for v in init]
+        n = max(int(niters), 0)
+        ring = torch.zeros((max(n, 1), 8), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            sv.plan.sync_stream()
+            if n > 0:
+                _dr_slab(SOLVER_PDR, n, sv, (z1, z2), bd, t, rho, gamma, 0 if problem == "l1" else 1, ring)
+            torch.cuda.synchronize(dev)
+        ret = [prox_box(z1, 1).to(b_rows.device)]                                                     # pdr:184
+        if kwargs.get("return_state"):
+            ret.append((z1.to(b_rows.device), z2.to(b_rows.device)))
+        if kwargs.get("return_losses"):
+            ret.append(combine_loss_records(ring[:n], float(H) * float(W), kwargs.get("group")).cpu())
+        return ret[0] if len(ret) == 1 else tuple(ret)
+    finally:
+        sv.close()
+
+
+def primal_dual_dr_splitting_slab(b_rows: torch.Tensor, kernel, image_shape: Tuple[int, int], niters: int = 1000, t: float = 3, rho: float = 0.4,
+                                  gamma: float = 0.03, **kwargs):
+    """primal_dual_dr_splitting (primal_dual_dr/algorithm.py:20-139) on row slabs: niters - 1
+    iterations.  init_state = (p, q) local slabs; without it the reference's draws (pddr:49-50) are made
+    for the whole image on every rank and the local rows kept.  Loss pair: (clip(p), b)."""
+    from .plan import stage
+    from .core.proximal_operators import prox_box
+    H, W = int(image_shape[0]), int(image_shape[1])
+    sv = SlabSolver(kernel, (H, W), t, t, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"))
+    try:
+        lay, dev, dt = sv.lay, sv.dev, sv.dt
+        bd = stage(b_rows, dev, dt)
+        init = kwargs.get("init_state")
+        if init is None:
+            init = [_local_rows(torch.rand((H, W), dtype=dt), lay), _local_rows(torch.rand((3, H, W), dtype=dt), lay)]
+        p, q = [stage(torch.as_tensor(v), dev, dt) for v in init]
+        n = max(int(niters) - 1, 0)
+        ring = torch.zeros((max(n, 1), 8), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            sv.plan.sync_stream()
+            if n > 0:
+                _dr_slab(SOLVER_PDDR, n, sv, (p, q), bd, t, rho, gamma, 0, ring)
+            torch.cuda.synchronize(dev)
+        ret = [prox_box(p, 1).to(b_rows.device)]                                                      # pddr:136
+        if kwargs.get("return_state"):
+            ret.append((p.to(b_rows.device), q.to(b_rows.device)))
+        if kwargs.get("return_losses"):
+            ret.append(combine_loss_records(ring[:n], float(H) * float(W), kwargs.get("group")).cpu())
+        return ret[0] if len(ret) == 1 else tuple(ret)
+    finally:
+        sv.close()

@@ -180,6 +180,39 @@ int ddn_pddr_run(ddn_plan* p, void* p_dev, void* q_dev, const void* b_dev,
                  int tol_kind, double tol, int first_loss_iter,
                  double* loss_ring_dev, int* iters_done_dev);
 
+/* ---- one image split into row slabs over several GPUs ------------------------------
+ * The reference solves a single 2-D image per call (multiplying_matrix.py:31) with whole-image
+ * fft2 / ifft2 (apply_periodic_conv_2d.py:3-28); these entry points are the two local halves of one
+ * iteration of admm:69-115 / pdr:94-129 / pddr:65-101 when the image's rows are spread over ranks.
+ * Every rank creates its plan with the FULL image size (batch 1) and sets the blur kernel and the
+ * resolvent as usual, so that its multipliers cover every frequency.  Rank r owns `rows`
+ * consecutive image rows (the same count on every rank) and a contiguous range of spectral tiles
+ * (ddn_slab_layout: tile_cols = C columns per tile, n_tiles = ceil((W/2+1)/C) tiles in all).
+ *
+ *   ddn_slab_rows   the fused row kernel of `solver` (0 admm, 1 pdr, 2 pddr) on the local rows.
+ *                   Iterate arrays are the local slabs: s0..s3 = (u, w, y, z) for admm, (z1, z2)
+ *                   for pdr, (p, q) for pddr, shapes [rows][W] and [3][rows][W]; b: [rows][W].
+ *                   consume / produce: whether the launch takes the solved pair in from
+ *                   spec_rows / leaves the next right-hand side in it (first launch of a loop:
+ *                   0 / 1, steady state 1 / 1, final ADMM solve 1 / 0 with sol_only = 1).
+ *                   spec_rows: complex [n_tiles][2][rows][C] — of every tile first the rows of the
+ *                   first half-spectrum, then of the second; the tiles of one destination rank
+ *                   are one contiguous block.
+ *   ddn_slab_cols   the column stage (forward transform, resolvent algebra, inverse transform) in
+ *                   place on spec_cols: complex [2][n_tiles_local][H][C], the tiles
+ *                   [tile_lo, tile_lo + n_tiles_local) of both half-spectra with all H rows.
+ *   ddn_slab_loss   record8[0..7] = l1, l2, mse, psnr (primary pair), then the secondary pair, of
+ *                   the LOCAL rows seen by the last consuming ddn_slab_rows launch; l1 and l2^2
+ *                   add up over ranks (mse and psnr are per-slab figures over the full pixel count).
+ * The exchange between the two buffers is an all-to-all owned by the caller (RCCL through
+ * torch.distributed in this package).  No early stop inside these calls. */
+int ddn_slab_layout(ddn_plan* p, int* tile_cols, int* n_tiles);
+int ddn_slab_rows(ddn_plan* p, int solver, int rows, void* spec_rows_dev, void* s0_dev, void* s1_dev, void* s2_dev, void* s3_dev,
+                  const void* b_dev, double t, double rho, double gamma, int objective, int consume, int produce,
+                  void* sol_out_dev, int sol_only);
+int ddn_slab_cols(ddn_plan* p, void* spec_cols_dev, int tile_lo, int n_tiles_local);
+int ddn_slab_loss(ddn_plan* p, int rows, double* record8_dev);
+
 /* Timing hook for bench.py: average duration in milliseconds, measured with HIP
  * events on the plan's stream, of the last *_run call's dominant kernel (the fused
  * row kernel) and of all its kernels; synchronises the stream.  Row launches that do

@@ -66,3 +66,66 @@ def test_world2_gloo_loss_allreduce():
     for r in range(world):
         ok, s1, s2 = out[r]
         assert ok and s1 is True and s2 is False
+
+
+# ------------------------------------------------------------------ row-slab decomposition of one image
+def _code(tile, spec, row, col):
+    return complex(1000.0 * tile + 100.0 * spec + col, float(row))
+
+
+def _slab_worker(rank, world, port, H, C, n_tiles, out):
+    from convex_optimization_amd.slab import SlabExchange, SlabLayout, combine_loss_records
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lay = SlabLayout(H, 2 * C * (n_tiles - 1), C, n_tiles, rank, world)
+        x = SlabExchange(lay, torch.complex64, "cpu")
+        for tl in range(n_tiles):
+            for s in range(2):
+                for r in range(lay.rows):
+                    for c in range(C):
+                        x.spec_rows[tl, s, r, c] = _code(tl, s, lay.row_lo + r, c)
+        sent = x.spec_rows.clone()
+        x.rows_to_cols()
+        ok_cols = True
+        for s in range(2):
+            for lt in range(lay.local_tiles):
+                for h in range(H):
+                    for c in range(C):
+                        ok_cols &= complex(x.spec_cols[s, lt, h, c]) == _code(lay.tile_lo + lt, s, h, c)
+        x.spec_rows.zero_()
+        x.cols_to_rows()
+        ok_back = torch.equal(x.spec_rows, sent)
+        # loss records: l1 and l2^2 add up over the slabs
+        local = torch.zeros(3, 8, dtype=torch.float64)
+        local[:, 0] = rank + 1.0
+        local[:, 1] = 3.0 if rank == 0 else 4.0
+        local[:, 4] = 2.0 * (rank + 1.0)
+        local[:, 5] = 1.0
+        tot = combine_loss_records(local, 100.0)
+        ok_loss = bool(torch.allclose(tot[:, 0], torch.full((3,), 3.0, dtype=torch.float64)) and torch.allclose(tot[:, 1], torch.full((3,), 5.0, dtype=torch.float64))
+                       and torch.allclose(tot[:, 2], torch.full((3,), 0.25, dtype=torch.float64)) and torch.allclose(tot[:, 5], torch.full((3,), 2.0 ** 0.5, dtype=torch.float64)))
+        out[rank] = (bool(ok_cols), bool(ok_back), ok_loss, lay.tile_spans)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,C,n_tiles", [(8, 4, 5), (6, 2, 2)])
+def test_world2_gloo_slab_transposes(H, C, n_tiles):
+    """rows -> columns all-to-all puts every rank's rows of a tile at their global row index; the way
+    back restores the row-side buffer; uneven tile spans (the tile of column W/2 makes the count odd)."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_slab_worker, args=(world, _free_port(), H, C, n_tiles, out), nprocs=world, join=True)
+    for r in range(world):
+        ok_cols, ok_back, ok_loss, spans = out[r]
+        assert ok_cols and ok_back and ok_loss
+        assert spans[0][0] == 0 and spans[-1][1] == n_tiles
+
+
+def test_slab_layout_rejects_ragged_rows():
+    from convex_optimization_amd.slab import SlabLayout
+    with pytest.raises(ValueError):
+        SlabLayout(10, 16, 4, 3, 0, 4)

@@ -1,0 +1,150 @@
+"""GPU parity tests of the row-slab decomposition of one image (several ranks share the rows of an
+image; the column stage runs after an all-to-all of the half-spectra).  Checked against the CPU oracle
+and against the single-GPU path on the same inputs: fp32 relative L2 <= 1e-5, fp64 <= 1e-11.  The
+two-rank cases run both ranks on the one GPU of the box with the gloo backend (its all-to-all is
+staged through host memory there); on a multi-GPU node the same code runs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ddn_oracle as O  # checker only
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    return O.rel_l2(np.asarray(a), np.asarray(b))
+
+
+def _problem(H, W, kname, dt, noise=0.05):
+    k = np.load(os.path.join(GOLDEN, "kernels.npz"))
+    kern = torch.from_numpy(k[kname])
+    torch.manual_seed(0)
+    img = torch.rand(1, H, W, dtype=dt)
+    b = O.add_gaussian_noise(O.circular_convolve2d(img, kern), 0.0, noise)[0].to(dt)
+    torch.manual_seed(7)
+    stA = tuple(torch.clamp(torch.randn(s, dtype=torch.float32), 0, 1).to(dt) for s in [(H, W), (H, W), (3, H, W), (3, H, W)])
+    stP = (torch.rand(H, W, dtype=dt), torch.rand(3, H, W, dtype=dt))
+    return kern, b, stA, stP
+
+
+def _run_slabs(S, kern, b, stA, stP, H, W, N, lo, rows, group=None):
+    """All three slab solvers on rows [lo, lo + rows); returns solutions and whole-image loss records."""
+    sl = slice(lo, lo + rows)
+    out = {}
+    out["admm"] = S.admm_solver_slab(b[sl], (H, W), "l1", kernel=kern, niters=N + 1, init_state=[v[..., sl, :] for v in stA], return_losses=True, group=group)
+    out["admm_l2"] = S.admm_solver_slab(b[sl], (H, W), "l2", kernel=kern, niters=N + 1, init_state=[v[..., sl, :] for v in stA], return_losses=True, group=group)
+    out["pdr"] = S.primal_dr_splitting_slab("l1", kern, b[sl], (H, W), niters=N, return_losses=True, group=group)
+    out["pddr"] = S.primal_dual_dr_splitting_slab(b[sl], kern, (H, W), niters=N + 1, init_state=[v[..., sl, :] for v in stP], return_losses=True, group=group)
+    return out
+
+
+def _oracle(kern, b, stA, stP, N):
+    ref = {}
+    lo = []
+    ref["admm"] = O.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, loss_function=O.psnr, losses=lo)
+    ref["admm_psnr"] = lo
+    ref["admm_l2"] = O.admm_solver(b, "l2", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA)
+    ref["pdr"] = O.primal_dr_splitting("l1", kern, b, niters=N)
+    ref["pddr"] = O.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP)
+    return ref
+
+
+@pytest.mark.parametrize("H,W,kname,dt", [(64, 64, "gauss9", torch.float32), (48, 80, "motion15_45", torch.float32), (64, 64, "gauss9", torch.float64),
+                                          (32, 1024, "motion15_45", torch.float32), (16, 4096, "motion15_45", torch.float32)])
+def test_one_rank_slab_path_vs_oracle(H, W, kname, dt):
+    """World size 1: the slab entry points (row stage on its own buffer layout, tile-range column stage)
+    reproduce the oracle; covers the LDS row kernels, the register-resident row kernels (W = 1024, 4096)
+    and fp64."""
+    import convex_optimization_amd.slab as S
+    from convex_optimization_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    N = 20
+    kern, b, stA, stP = _problem(H, W, kname, dt)
+    got = _run_slabs(S, kern, b, stA, stP, H, W, N, 0, H)
+    if dt == torch.float32:
+        ref = _oracle(kern, b, stA, stP, N)
+        tol = 1e-5
+    else:
+        # fp64 parity with the reference needs its complex64-valued eigen arrays injected, which the slab
+        # path does not take: fp64 is held to the single-GPU path (device-built eigen arrays in double)
+        import convex_optimization_amd as pkg
+        ref = {}
+        ref["admm"], ref["admm_psnr"] = pkg.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, return_losses=True)
+        ref["admm_l2"] = pkg.admm_solver(b, "l2", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA)
+        ref["pdr"] = pkg.primal_dr_splitting("l1", kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0)
+        ref["pddr"] = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP, tol=-1.0)
+        tol = 1e-11
+    for name in ("admm", "admm_l2", "pdr", "pddr"):
+        assert rel(got[name][0].numpy(), ref[name].numpy()) < tol, name
+    rec = got["admm"][1].numpy()           # [N][8]; slot i = iteration i + 1; the reference records i > 1
+    assert np.allclose(rec[1:, 3], np.asarray(ref["admm_psnr"], dtype=np.float64), rtol=2e-5)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _two_rank_worker(rank, world, port, H, W, kname, dtname, N, out):
+    import torch.distributed as dist
+    import convex_optimization_amd.slab as S
+    import convex_optimization_amd as pkg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dt = getattr(torch, dtname)
+        kern, b, stA, stP = _problem(H, W, kname, dt)
+        rows = H // world
+        lo = rank * rows
+        got = _run_slabs(S, kern, b, stA, stP, H, W, N, lo, rows)
+        sl = slice(lo, lo + rows)
+        # the single-GPU path on the whole image, same inputs
+        one = {}
+        one["admm"], la = pkg.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, return_losses=True)
+        one["admm_l2"] = pkg.admm_solver(b, "l2", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA)
+        one["pdr"] = pkg.primal_dr_splitting("l1", kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0)
+        one["pddr"] = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP, tol=-1.0)
+        res = {name: rel(got[name][0].numpy(), one[name][sl].numpy()) for name in one}
+        if H * W <= 128 * 128 and dtname == "float32":
+            ref = _oracle(kern, b, stA, stP, N)
+            for name in ("admm", "admm_l2", "pdr", "pddr"):
+                res["oracle_" + name] = rel(got[name][0].numpy(), ref[name][sl].numpy())
+        rec = got["admm"][1].numpy()
+        res["psnr"] = float(np.max(np.abs(rec[1:, 3] - np.asarray(la, dtype=np.float64)) / np.abs(np.asarray(la, dtype=np.float64))))
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,W,kname,dtname", [(64, 96, "gauss9", "float32"), (64, 64, "motion15_45", "float64"), (512, 1024, "motion15_45", "float32")])
+def test_two_ranks_share_one_image(H, W, kname, dtname):
+    """Two ranks, each owning half of the rows, against the single-GPU solve of the whole image (and the
+    oracle at the small sizes): all-to-all both ways around every column stage, uneven tile spans,
+    whole-image loss records from per-slab sums."""
+    import torch.multiprocessing as mp
+    world, N = 2, 20
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_two_rank_worker, args=(world, _free_port(), H, W, kname, dtname, N, out), nprocs=world, join=True)
+    tol = 1e-5 if dtname == "float32" else 1e-11
+    for r in range(world):
+        res = dict(out[r])
+        for name, v in res.items():
+            if name.startswith("oracle_"):
+                assert v < 1e-5, (r, name, v)
+            elif name == "psnr":
+                assert v < 2e-5, (r, name, v)
+            else:
+                assert v < tol, (r, name, v)

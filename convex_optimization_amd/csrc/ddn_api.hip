@@ -1025,6 +1025,30 @@ int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles) {
     if (!p->have_K || !p->have_G) return fail(DDN_E_STATE, "slab_cols: operators not set");
     if (p->injected) return fail(DDN_E_UNSUPPORTED, "slab_cols: injected eigen arrays are not supported");
     if (ntiles == 0) return DDN_OK;
+    if constexpr (sizeof(T) == 4) {
+        // H = 4096 / 512-2048: the register-resident column kernels, pointed at the local columns (their
+        // multipliers are column-major, so a column range is a pointer offset; column W/2 stays in its tile)
+        const bool wave1 = wcol_ready(p), waven = !wave1 && wcoln_ready(p);
+        if ((wave1 || waven) && p->Gcm_ok && p->cs > 2) {
+            const int col_lo = tile_lo << p->cs;
+            wcol::Args w;
+            std::memset(&w, 0, sizeof(w));
+            w.S0 = (cx<float>*)spec;
+            w.S1 = (cx<float>*)spec + (size_t)ntiles * ((size_t)p->H << p->cs);
+            w.eKc = (const cx<float>*)p->eKc + (size_t)col_lo * wcol::kColPitch;
+            w.wtw = (const cx<float>*)(wave1 ? p->wtw : p->wtwH);
+            w.ed2 = (const float*)p->ed2 + col_lo;
+            w.cK = (float)p->g_cK; w.cD = (float)p->g_cD; w.gscale = (float)(1.0 / ((double)p->H * (double)p->W));
+            w.lay = layout_of(p);
+            w.lay.ntile = ntiles;
+            w.Wh = std::min(p->Wh - col_lo, ntiles << p->cs);
+            w.batch = 1;
+            w.scale = 1.f;
+            w.lf = no_loss();
+            TimerScope ts(p, false);
+            return waven ? wcoln_launch(p->stream, COL_RES2, w) : wcol_launch(p->stream, COL_RES2, w);
+        }
+    }
     // the plan's own fields are pointed at the local tile range for the duration of the call; the
     // multipliers are offset to the same tiles, which also selects the tile-generic column kernels
     struct Swap {

@@ -87,11 +87,17 @@ class SlabExchange:
 
     def rows_to_cols(self):
         """Every rank's rows of my tiles -> spec_cols (all H rows of the local tiles)."""
+        if self.lay.world == 1:  # nothing to exchange: one layout copy
+            self._cols_view().copy_(self.spec_rows.unsqueeze(0).permute(2, 1, 0, 3, 4))
+            return
         self._a2a(self._stage, self.spec_rows, self._col_splits, self._row_splits)
         self._cols_view().copy_(self._stage.permute(2, 1, 0, 3, 4))
 
     def cols_to_rows(self):
         """spec_cols -> my rows of every tile in spec_rows."""
+        if self.lay.world == 1:
+            self.spec_rows.unsqueeze(0).copy_(self._cols_view().permute(2, 1, 0, 3, 4))
+            return
         self._stage.copy_(self._cols_view().permute(2, 1, 0, 3, 4))
         self._a2a(self.spec_rows, self._stage, self._row_splits, self._col_splits)
 

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Timing of the row-slab decomposition of ONE image (ADMM, fp32): per-stage device time of an
+iteration — fused row kernel on the local rows, all-to-all + layout copies, local column stage.
+
+  python tools/tools_slab_bench.py --size 4096 --iters 50                 (one rank: the cost of the slab layout itself)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 tools/tools_slab_bench.py --size 8192
+
+Strong scaling: the image is fixed, every rank owns size / P rows.  Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+    import convex_optimization_amd.slab as S
+    from convex_optimization_amd.core.blur import create_motion_blur_kernel
+
+    H = W = args.size
+    kern = create_motion_blur_kernel(15, 45)
+    sv = S.SlabSolver(kern, (H, W), 1, 1, dtype=torch.float32, device=dev)
+    rows = sv.lay.rows
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2000 + rank)
+    b = torch.rand((rows, W), device=dev, generator=gen)
+    st = [torch.rand((rows, W), device=dev, generator=gen), torch.rand((rows, W), device=dev, generator=gen),
+          torch.rand((3, rows, W), device=dev, generator=gen), torch.rand((3, rows, W), device=dev, generator=gen)]
+    sv.plan.sync_stream()
+    par = (18.0, 0.001, 0.5, 0)
+
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    sv.rows(S.SOLVER_ADMM, st, b, *par, False, True)
+    t_rows = t_x = t_cols = 0.0
+    wall = 0.0
+    for it in range(args.warmup + args.iters):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        e0 = ev()
+        sv.xch.rows_to_cols()
+        e1 = ev()
+        from convex_optimization_amd.plan import _ptr
+        sv.L.check(sv.L.lib().ddn_slab_cols(sv.plan._h, _ptr(sv.xch.spec_cols), sv.lay.tile_lo, sv.lay.local_tiles))
+        e2 = ev()
+        sv.xch.cols_to_rows()
+        e3 = ev()
+        sv.rows(S.SOLVER_ADMM, st, b, *par, True, True)
+        e4 = ev()
+        torch.cuda.synchronize(dev)
+        if it >= args.warmup:
+            wall += time.perf_counter() - t0
+            t_x += e0.elapsed_time(e1) + e2.elapsed_time(e3)
+            t_cols += e1.elapsed_time(e2)
+            t_rows += e3.elapsed_time(e4)
+    n = args.iters
+    el = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    sec = float(el.item())
+    if rank == 0:
+        print(json.dumps({"metric": "Mpixel-iterations/s, ADMM, one image in row slabs", "value": H * W * n / sec / 1e6, "n_gpus": world, "scaling": "strong",
+                          "size": args.size, "rows_per_rank": rows, "ms_per_iter": sec / n * 1e3,
+                          "stage_ms": {"rows": t_rows / n, "exchange": t_x / n, "cols": t_cols / n},
+                          "tile_cols": sv.lay.C, "n_tiles": sv.lay.n_tiles}), flush=True)
+    sv.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

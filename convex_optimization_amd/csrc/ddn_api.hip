@@ -1019,17 +1019,19 @@ int slab_rows_impl(ddn_plan* p, int solver, int rows, void* spec, void* s0, void
     return fail(DDN_E_ARG, "slab_rows: unknown solver");
 }
 
-// Column stage of the resolvent solvers on tiles [tile_lo, tile_lo + ntiles) of the image's half-spectra.
-template <typename T>
-int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles) {
-    if (!p->have_K || !p->have_G) return fail(DDN_E_STATE, "slab_cols: operators not set");
+// Column stage on tiles [tile_lo, tile_lo + ntiles) of the image's half-spectra: MODE COL_RES2 (the
+// resolvent solvers; spec holds both spectra) or COL_MUL (Chambolle-Pock: one spectrum times eK or conj(eK)).
+template <typename T, int MODE>
+int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles, int conj_mult) {
+    if (!p->have_K || (MODE == COL_RES2 && !p->have_G)) return fail(DDN_E_STATE, "slab_cols: operators not set");
     if (p->injected) return fail(DDN_E_UNSUPPORTED, "slab_cols: injected eigen arrays are not supported");
     if (ntiles == 0) return DDN_OK;
+    const T scale = MODE == COL_MUL ? (T)(1.0 / ((double)p->H * (double)p->W)) : (T)1;
     if constexpr (sizeof(T) == 4) {
         // H = 4096 / 512-2048: the register-resident column kernels, pointed at the local columns (their
         // multipliers are column-major, so a column range is a pointer offset; column W/2 stays in its tile)
         const bool wave1 = wcol_ready(p), waven = !wave1 && wcoln_ready(p);
-        if ((wave1 || waven) && p->Gcm_ok && p->cs > 2) {
+        if ((wave1 || waven) && (MODE == COL_MUL || p->Gcm_ok) && p->cs > 2) {
             const int col_lo = tile_lo << p->cs;
             wcol::Args w;
             std::memset(&w, 0, sizeof(w));
@@ -1043,14 +1045,15 @@ int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles) {
             w.lay.ntile = ntiles;
             w.Wh = std::min(p->Wh - col_lo, ntiles << p->cs);
             w.batch = 1;
-            w.scale = 1.f;
+            w.conj_mult = conj_mult;
+            w.scale = (float)scale;
             w.lf = no_loss();
             TimerScope ts(p, false);
-            return waven ? wcoln_launch(p->stream, COL_RES2, w) : wcol_launch(p->stream, COL_RES2, w);
+            return waven ? wcoln_launch(p->stream, MODE, w) : wcol_launch(p->stream, MODE, w);
         }
     }
     // the plan's own fields are pointed at the local tile range for the duration of the call; the
-    // multipliers are offset to the same tiles, which also selects the tile-generic column kernels
+    // multipliers are offset to the same tiles, and the tile-generic column kernels are selected
     struct Swap {
         ddn_plan* p; void* S0; void* S1; int ntile;
         explicit Swap(ddn_plan* q) : p(q), S0(q->S0), S1(q->S1), ntile(q->ntile) { p->slab_cols = true; }
@@ -1061,7 +1064,34 @@ int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles) {
     p->S1 = (cx<T>*)spec + (size_t)ntiles * tile_elems;
     p->ntile = ntiles;
     const size_t off = (size_t)tile_lo * tile_elems;
+    if (MODE == COL_MUL) return col_stage<T, COL_MUL>(p, 1, (const cx<T>*)p->eK + off, nullptr, nullptr, conj_mult, scale, no_loss());
     return col_stage<T, COL_RES2>(p, 1, (const cx<T>*)p->eK + off, (const T*)p->G + off, nullptr, 0, (T)1, no_loss());
+}
+
+// Chambolle-Pock row step (cp:58-92) on the local rows; one half-spectrum, laid out [tile][rows][C].
+template <typename T>
+int slab_rows_cp_impl(ddn_plan* p, int rows, void* spec, void* x, void* z, void* y, const void* b, double t, double s, double gamma,
+                      int objective, int step, int consume, int produce) {
+    if (!p->have_K) return fail(DDN_E_STATE, "slab_rows_cp: operators not set");
+    if (p->injected) return fail(DDN_E_UNSUPPORTED, "slab_rows_cp: injected eigen arrays are not supported");
+    SlabRows guard(p, rows);
+    const size_t plane = (size_t)rows * p->W;
+    RowCfg cfg;
+    const bool al = aligned16(x) && aligned16(z) && aligned16(y) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
+    if (!row_cfg<T>(p, al, (rows + 1) / 2, cfg, true)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    CpArgs<T> a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = (T*)x; a.z = (T*)z; a.y0 = (T*)y; a.y1 = (T*)y + plane; a.y2 = (T*)y + 2 * plane; a.b = (const T*)b;
+    a.t = (T)t; a.s = (T)s; a.is = (T)(1.0 / s); a.isg = (T)((1.0 / s) * gamma); a.l2div = (T)(2 * (1.0 / s) + 1); a.objective = objective;
+    a.step = step;
+    RowCommon<T> c = row_common<T>(p, cfg.V, consume != 0, produce != 0);
+    c.stop = nullptr;
+    c.S0 = (cx<T>*)spec;
+    c.S1 = nullptr;
+    c.lay.H = rows;
+    c.nyqd = nullptr;
+    c.ilv = 0;
+    return launch_cp_row<T>(p, cfg, c, a);
 }
 
 }  // namespace
@@ -1345,8 +1375,28 @@ int ddn_slab_cols(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local) 
     if (p->batch != 1) return fail(DDN_E_ARG, "slab_cols: the plan must hold one image");
     if (tile_lo < 0 || n_tiles_local < 0 || tile_lo + n_tiles_local > p->ntile) return fail(DDN_E_ARG, "slab_cols: bad tile range");
     if (p->tile_pad_rows) return fail(DDN_E_UNSUPPORTED, "slab_cols: padded tiles are not supported");
-    if (p->dtype == DDN_F32) return slab_cols_impl<float>(p, spec_cols, tile_lo, n_tiles_local);
-    return slab_cols_impl<double>(p, spec_cols, tile_lo, n_tiles_local);
+    if (p->dtype == DDN_F32) return slab_cols_impl<float, COL_RES2>(p, spec_cols, tile_lo, n_tiles_local, 0);
+    return slab_cols_impl<double, COL_RES2>(p, spec_cols, tile_lo, n_tiles_local, 0);
+}
+
+int ddn_slab_cols_multiply(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local, int conj) {
+    if (!p || (!spec_cols && n_tiles_local > 0)) return fail(DDN_E_ARG, "slab_cols_multiply: null argument");
+    if (p->batch != 1) return fail(DDN_E_ARG, "slab_cols_multiply: the plan must hold one image");
+    if (tile_lo < 0 || n_tiles_local < 0 || tile_lo + n_tiles_local > p->ntile) return fail(DDN_E_ARG, "slab_cols_multiply: bad tile range");
+    if (p->tile_pad_rows) return fail(DDN_E_UNSUPPORTED, "slab_cols_multiply: padded tiles are not supported");
+    if (p->dtype == DDN_F32) return slab_cols_impl<float, COL_MUL>(p, spec_cols, tile_lo, n_tiles_local, conj ? 1 : 0);
+    return slab_cols_impl<double, COL_MUL>(p, spec_cols, tile_lo, n_tiles_local, conj ? 1 : 0);
+}
+
+int ddn_slab_rows_cp(ddn_plan* p, int rows, void* spec_rows, void* x, void* z, void* y, const void* b, double t, double s, double gamma,
+                     int objective, int step, int consume, int produce) {
+    if (!p || !spec_rows || !x || !z || !y || !b) return fail(DDN_E_ARG, "slab_rows_cp: null argument");
+    if (objective != DDN_OBJ_L1 && objective != DDN_OBJ_L2) return fail(DDN_E_ARG, "Invalid objective function. Choose 'l1' or 'l2'.");
+    if (p->batch != 1) return fail(DDN_E_ARG, "slab_rows_cp: the plan must hold one image");
+    if (rows < 1 || rows > p->H) return fail(DDN_E_ARG, "slab_rows_cp: bad row count");
+    if (p->tile_pad_rows) return fail(DDN_E_UNSUPPORTED, "slab_rows_cp: padded tiles are not supported");
+    if (p->dtype == DDN_F32) return slab_rows_cp_impl<float>(p, rows, spec_rows, x, z, y, b, t, s, gamma, objective, step, consume, produce);
+    return slab_rows_cp_impl<double>(p, rows, spec_rows, x, z, y, b, t, s, gamma, objective, step, consume, produce);
 }
 
 int ddn_slab_loss(ddn_plan* p, int rows, double* record8) {

@@ -58,12 +58,13 @@ def _world(group=None) -> Tuple[int, int]:
 class SlabExchange:
     """The two spectral buffers of a rank and the all-to-all transposes between them."""
 
-    def __init__(self, lay: SlabLayout, complex_dtype: torch.dtype, device, group=None):
-        self.lay, self.group = lay, group
-        self.spec_rows = torch.zeros((lay.n_tiles, 2, lay.rows, lay.C), dtype=complex_dtype, device=device)
-        self.spec_cols = torch.zeros((2, lay.local_tiles, lay.H, lay.C), dtype=complex_dtype, device=device)
-        self._stage = torch.zeros((lay.world, lay.local_tiles, 2, lay.rows, lay.C), dtype=complex_dtype, device=device)
-        per_tile = 2 * lay.rows * lay.C * 2  # real numbers per tile of the row-side layout
+    def __init__(self, lay: SlabLayout, complex_dtype: torch.dtype, device, group=None, n_spectra: int = 2):
+        self.lay, self.group, self.ns = lay, group, int(n_spectra)
+        ns = self.ns
+        self.spec_rows = torch.zeros((lay.n_tiles, ns, lay.rows, lay.C), dtype=complex_dtype, device=device)
+        self.spec_cols = torch.zeros((ns, lay.local_tiles, lay.H, lay.C), dtype=complex_dtype, device=device)
+        self._stage = torch.zeros((lay.world, lay.local_tiles, ns, lay.rows, lay.C), dtype=complex_dtype, device=device) if lay.world > 1 else None
+        per_tile = ns * lay.rows * lay.C * 2  # real numbers per tile of the row-side layout
         self._row_splits = [(hi - lo) * per_tile for lo, hi in lay.tile_spans]
         self._col_splits = [lay.local_tiles * per_tile] * lay.world
 
@@ -82,8 +83,8 @@ class SlabExchange:
         dist.all_to_all_single(o, i, list(out_splits), list(in_splits), group=self.group)
 
     def _cols_view(self) -> torch.Tensor:
-        l = self.lay  # [2][tiles][H][C] seen as [2][tiles][source rank][rows][C]
-        return self.spec_cols.view(2, l.local_tiles, l.world, l.rows, l.C)
+        l = self.lay  # [spectra][tiles][H][C] seen as [spectra][tiles][source rank][rows][C]
+        return self.spec_cols.view(self.ns, l.local_tiles, l.world, l.rows, l.C)
 
     def rows_to_cols(self):
         """Every rank's rows of my tiles -> spec_cols (all H rows of the local tiles)."""
@@ -128,7 +129,8 @@ def combine_loss_records(local: torch.Tensor, npix: float, group=None) -> torch.
 class SlabSolver:
     """Plan, buffers and the two local stages of one slab-decomposed solve (fp32 or fp64)."""
 
-    def __init__(self, kernel, image_shape: Tuple[int, int], t_resolvent: float, s_resolvent: float, dtype=torch.float32, device=None, group=None):
+    def __init__(self, kernel, image_shape: Tuple[int, int], t_resolvent: float, s_resolvent: float, dtype=torch.float32, device=None, group=None,
+                 n_spectra: int = 2):
         from . import _lib as L
         from .plan import Plan, compute_device, real_dtype
         self.L = L
@@ -144,7 +146,7 @@ class SlabSolver:
         c, n = C.c_int(0), C.c_int(0)
         L.check(L.lib().ddn_slab_layout(self.plan._h, C.byref(c), C.byref(n)))
         self.lay = SlabLayout(H, W, c.value, n.value, self.rank, self.world)
-        self.xch = SlabExchange(self.lay, torch.complex128 if self.dt == torch.float64 else torch.complex64, self.dev, group)
+        self.xch = SlabExchange(self.lay, torch.complex128 if self.dt == torch.float64 else torch.complex64, self.dev, group, n_spectra)
         self._rec = torch.zeros((8,), dtype=torch.float64, device=self.dev)
 
     def close(self):
@@ -162,6 +164,18 @@ class SlabSolver:
         from .plan import _ptr
         self.xch.rows_to_cols()
         self.L.check(self.L.lib().ddn_slab_cols(self.plan._h, _ptr(self.xch.spec_cols), self.lay.tile_lo, self.lay.local_tiles))
+        self.xch.cols_to_rows()
+
+    def rows_cp(self, state, b: torch.Tensor, t: float, s: float, gamma: float, objective: int, step: int, consume: bool, produce: bool):
+        from .plan import _ptr
+        self.L.check(self.L.lib().ddn_slab_rows_cp(self.plan._h, self.lay.rows, _ptr(self.xch.spec_rows), _ptr(state[0]), _ptr(state[1]), _ptr(state[2]), _ptr(b),
+                                                   float(t), float(s), float(gamma), int(objective), int(step), int(consume), int(produce)))
+
+    def column_multiply(self, conj: bool):
+        """rows -> columns all-to-all, spectrum times eK (or its conjugate) on the local tiles, all-to-all back."""
+        from .plan import _ptr
+        self.xch.rows_to_cols()
+        self.L.check(self.L.lib().ddn_slab_cols_multiply(self.plan._h, _ptr(self.xch.spec_cols), self.lay.tile_lo, self.lay.local_tiles, int(conj)))
         self.xch.cols_to_rows()
 
     def loss_record(self, out: torch.Tensor):
@@ -299,6 +313,53 @@ def primal_dual_dr_splitting_slab(b_rows: torch.Tensor, kernel, image_shape: Tup
         ret = [prox_box(p, 1).to(b_rows.device)]                                                      # pddr:136
         if kwargs.get("return_state"):
             ret.append((p.to(b_rows.device), q.to(b_rows.device)))
+        if kwargs.get("return_losses"):
+            ret.append(combine_loss_records(ring[:n], float(H) * float(W), kwargs.get("group")).cpu())
+        return ret[0] if len(ret) == 1 else tuple(ret)
+    finally:
+        sv.close()
+
+
+def chambolle_pock_slab(b_rows: torch.Tensor, kernel, image_shape: Tuple[int, int], objective_function: str = "l1", t: float = 0.4, s: float = 0.7,
+                        gamma: float = 0.01, max_iter: int = 500, **kwargs):
+    """chambolle_pock (chambolle_pock/algorithm.py:21-143) on row slabs: max_iter - 1 iterations, two column
+    stages (K, then K^T) and therefore four all-to-all exchanges per iteration.  b_rows: (H / P, W); returns
+    this rank's rows of x with the reference's leading dimension, (1, H / P, W).  init_state = (x, z, y) local
+    slabs; without it the reference's draws (cp:50-52) are made for the whole image on every rank and the
+    local rows kept.  Loss pair: (x_next, b) (cp:96)."""
+    if objective_function not in ("l1", "l2"):
+        raise ValueError("Invalid objective function. Choose 'l1' or 'l2'.")
+    from . import _lib as L
+    from .plan import stage
+    H, W = int(image_shape[0]), int(image_shape[1])
+    sv = SlabSolver(kernel, (H, W), 1, 1, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
+                    n_spectra=1)
+    try:
+        lay, dev, dt = sv.lay, sv.dev, sv.dt
+        b2 = b_rows.reshape(lay.rows, W)
+        init = kwargs.get("init_state")
+        if init is None:
+            init = [_local_rows(torch.rand(size=shape, dtype=dt), lay) for shape in ((H, W), (H, W), (3, H, W))]
+        x, z, y = [stage(torch.as_tensor(v), dev, dt) for v in init]
+        bd = stage(b2, dev, dt)
+        n = max(int(max_iter) - 1, 0)
+        obj = L.OBJ[objective_function]
+        ring = torch.zeros((max(n, 1), 8), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            sv.plan.sync_stream()
+            st = (x, z, y)
+            if n > 0:
+                sv.rows_cp(st, bd, t, s, gamma, obj, 1, False, True)
+                for c in range(1, n + 1):
+                    sv.column_multiply(False)
+                    sv.rows_cp(st, bd, t, s, gamma, obj, 0, True, True)
+                    sv.column_multiply(True)
+                    sv.rows_cp(st, bd, t, s, gamma, obj, 1, True, c < n)
+                    sv.loss_record(ring[c - 1])
+            torch.cuda.synchronize(dev)
+        ret = [x.to(b_rows.device).unsqueeze(0)]
+        if kwargs.get("return_state"):
+            ret.append(tuple(v.to(b_rows.device) for v in st))
         if kwargs.get("return_losses"):
             ret.append(combine_loss_records(ring[:n], float(H) * float(W), kwargs.get("group")).cpu())
         return ret[0] if len(ret) == 1 else tuple(ret)

@@ -212,6 +212,18 @@ int ddn_slab_rows(ddn_plan* p, int solver, int rows, void* spec_rows_dev, void* 
                   void* sol_out_dev, int sol_only);
 int ddn_slab_cols(ddn_plan* p, void* spec_cols_dev, int tile_lo, int n_tiles_local);
 int ddn_slab_loss(ddn_plan* p, int rows, double* record8_dev);
+/* The same for chambolle_pock (cp:58-92), whose iteration has two column stages and one half-spectrum:
+ * spec_rows: complex [n_tiles][rows][C]; spec_cols: complex [n_tiles_local][H][C].
+ *   ddn_slab_rows_cp        step = 1: the primal step (consumes K^T y^ ... produces the right-hand side of the
+ *                           dual step), step = 0: the dual step; x, z: [rows][W], y: [3][rows][W].
+ *                           A loop is: (step 1, consume 0, produce 1), then per iteration
+ *                           cols_multiply(conj 0), (step 0, 1, 1), cols_multiply(conj 1), (step 1, 1, produce
+ *                           unless last); ddn_slab_loss after a consuming step-1 launch gives (x_next, b).
+ *   ddn_slab_cols_multiply  spectrum <- eK (conj = 0) or conj(eK) (conj = 1) times spectrum / (H W), between a
+ *                           forward and an inverse column transform, on the local tile range. */
+int ddn_slab_rows_cp(ddn_plan* p, int rows, void* spec_rows_dev, void* x_dev, void* z_dev, void* y_dev, const void* b_dev,
+                     double t, double s, double gamma, int objective, int step, int consume, int produce);
+int ddn_slab_cols_multiply(ddn_plan* p, void* spec_cols_dev, int tile_lo, int n_tiles_local, int conj);
 
 /* Timing hook for bench.py: average duration in milliseconds, measured with HIP
  * events on the plan's stream, of the last *_run call's dominant kernel (the fused

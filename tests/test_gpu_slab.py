@@ -30,10 +30,11 @@ def _problem(H, W, kname, dt, noise=0.05):
     torch.manual_seed(7)
     stA = tuple(torch.clamp(torch.randn(s, dtype=torch.float32), 0, 1).to(dt) for s in [(H, W), (H, W), (3, H, W), (3, H, W)])
     stP = (torch.rand(H, W, dtype=dt), torch.rand(3, H, W, dtype=dt))
-    return kern, b, stA, stP
+    stC = (torch.rand(H, W, dtype=dt), torch.rand(H, W, dtype=dt), torch.rand(3, H, W, dtype=dt))
+    return kern, b, stA, stP, stC
 
 
-def _run_slabs(S, kern, b, stA, stP, H, W, N, lo, rows, group=None):
+def _run_slabs(S, kern, b, stA, stP, stC, H, W, N, lo, rows, group=None):
     """All three slab solvers on rows [lo, lo + rows); returns solutions and whole-image loss records."""
     sl = slice(lo, lo + rows)
     out = {}
@@ -41,10 +42,22 @@ def _run_slabs(S, kern, b, stA, stP, H, W, N, lo, rows, group=None):
     out["admm_l2"] = S.admm_solver_slab(b[sl], (H, W), "l2", kernel=kern, niters=N + 1, init_state=[v[..., sl, :] for v in stA], return_losses=True, group=group)
     out["pdr"] = S.primal_dr_splitting_slab("l1", kern, b[sl], (H, W), niters=N, return_losses=True, group=group)
     out["pddr"] = S.primal_dual_dr_splitting_slab(b[sl], kern, (H, W), niters=N + 1, init_state=[v[..., sl, :] for v in stP], return_losses=True, group=group)
+    out["cp"] = S.chambolle_pock_slab(b[sl], kern, (H, W), max_iter=N + 1, init_state=[v[..., sl, :] for v in stC], return_losses=True, group=group)
+    out["cp"] = (out["cp"][0][0], out["cp"][1])   # (1, rows, W) -> (rows, W)
     return out
 
 
-def _oracle(kern, b, stA, stP, N):
+def _single_gpu(pkg, kern, b, stA, stP, stC, N):
+    one = {}
+    one["admm"], one["admm_psnr"] = pkg.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, return_losses=True)
+    one["admm_l2"] = pkg.admm_solver(b, "l2", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA)
+    one["pdr"] = pkg.primal_dr_splitting("l1", kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0)
+    one["pddr"] = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP, tol=-1.0)
+    one["cp"] = pkg.chambolle_pock_solver(b[None], kern, max_iter=N + 1, init_state=stC)[0]
+    return one
+
+
+def _oracle(kern, b, stA, stP, stC, N):
     ref = {}
     lo = []
     ref["admm"] = O.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, loss_function=O.psnr, losses=lo)
@@ -52,6 +65,7 @@ def _oracle(kern, b, stA, stP, N):
     ref["admm_l2"] = O.admm_solver(b, "l2", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA)
     ref["pdr"] = O.primal_dr_splitting("l1", kern, b, niters=N)
     ref["pddr"] = O.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP)
+    ref["cp"] = O.chambolle_pock(b[None], kern, max_iter=N + 1, init_state=stC)[0]
     return ref
 
 
@@ -67,22 +81,18 @@ def test_one_rank_slab_path_vs_oracle(H, W, kname, dt):
     _lib.lib()
     assert torch.cuda.is_available()
     N = 20
-    kern, b, stA, stP = _problem(H, W, kname, dt)
-    got = _run_slabs(S, kern, b, stA, stP, H, W, N, 0, H)
+    kern, b, stA, stP, stC = _problem(H, W, kname, dt)
+    got = _run_slabs(S, kern, b, stA, stP, stC, H, W, N, 0, H)
     if dt == torch.float32:
-        ref = _oracle(kern, b, stA, stP, N)
+        ref = _oracle(kern, b, stA, stP, stC, N)
         tol = 1e-5
     else:
         # fp64 parity with the reference needs its complex64-valued eigen arrays injected, which the slab
         # path does not take: fp64 is held to the single-GPU path (device-built eigen arrays in double)
         import convex_optimization_amd as pkg
-        ref = {}
-        ref["admm"], ref["admm_psnr"] = pkg.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, return_losses=True)
-        ref["admm_l2"] = pkg.admm_solver(b, "l2", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA)
-        ref["pdr"] = pkg.primal_dr_splitting("l1", kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0)
-        ref["pddr"] = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP, tol=-1.0)
+        ref = _single_gpu(pkg, kern, b, stA, stP, stC, N)
         tol = 1e-11
-    for name in ("admm", "admm_l2", "pdr", "pddr"):
+    for name in ("admm", "admm_l2", "pdr", "pddr", "cp"):
         assert rel(got[name][0].numpy(), ref[name].numpy()) < tol, name
     rec = got["admm"][1].numpy()           # [N][8]; slot i = iteration i + 1; the reference records i > 1
     assert np.allclose(rec[1:, 3], np.asarray(ref["admm_psnr"], dtype=np.float64), rtol=2e-5)
@@ -106,21 +116,17 @@ def _two_rank_worker(rank, world, port, H, W, kname, dtname, N, out):
     try:
         torch.cuda.set_device(0)
         dt = getattr(torch, dtname)
-        kern, b, stA, stP = _problem(H, W, kname, dt)
+        kern, b, stA, stP, stC = _problem(H, W, kname, dt)
         rows = H // world
         lo = rank * rows
-        got = _run_slabs(S, kern, b, stA, stP, H, W, N, lo, rows)
+        got = _run_slabs(S, kern, b, stA, stP, stC, H, W, N, lo, rows)
         sl = slice(lo, lo + rows)
-        # the single-GPU path on the whole image, same inputs
-        one = {}
-        one["admm"], la = pkg.admm_solver(b, "l1", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, return_losses=True)
-        one["admm_l2"] = pkg.admm_solver(b, "l2", kernel=kern, niters=N + 1, tol=-1.0, init_state=stA)
-        one["pdr"] = pkg.primal_dr_splitting("l1", kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0)
-        one["pddr"] = pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP, tol=-1.0)
+        one = _single_gpu(pkg, kern, b, stA, stP, stC, N)   # the single-GPU path on the whole image, same inputs
+        la = one.pop("admm_psnr")
         res = {name: rel(got[name][0].numpy(), one[name][sl].numpy()) for name in one}
         if H * W <= 128 * 128 and dtname == "float32":
-            ref = _oracle(kern, b, stA, stP, N)
-            for name in ("admm", "admm_l2", "pdr", "pddr"):
+            ref = _oracle(kern, b, stA, stP, stC, N)
+            for name in ("admm", "admm_l2", "pdr", "pddr", "cp"):
                 res["oracle_" + name] = rel(got[name][0].numpy(), ref[name][sl].numpy())
         rec = got["admm"][1].numpy()
         res["psnr"] = float(np.max(np.abs(rec[1:, 3] - np.asarray(la, dtype=np.float64)) / np.abs(np.asarray(la, dtype=np.float64))))

@@ -973,7 +973,6 @@ template <typename T>
 int slab_rows_impl(ddn_plan* p, int solver, int rows, void* spec, void* s0, void* s1, void* s2, void* s3, const void* b,
                    double t, double rho, double gamma, int objective, int consume, int produce, void* sol, int sol_only) {
     if (!p->have_K || !p->have_G) return fail(DDN_E_STATE, "slab_rows: operators not set");
-    if (p->injected) return fail(DDN_E_UNSUPPORTED, "slab_rows: injected eigen arrays are not supported");
     SlabRows guard(p, rows);  // row_cfg / row_common size the launch from p->H
     const size_t plane = (size_t)rows * p->W;
     RowCfg cfg;
@@ -1024,7 +1023,6 @@ int slab_rows_impl(ddn_plan* p, int solver, int rows, void* spec, void* s0, void
 template <typename T, int MODE>
 int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles, int conj_mult) {
     if (!p->have_K || (MODE == COL_RES2 && !p->have_G)) return fail(DDN_E_STATE, "slab_cols: operators not set");
-    if (p->injected) return fail(DDN_E_UNSUPPORTED, "slab_cols: injected eigen arrays are not supported");
     if (ntiles == 0) return DDN_OK;
     const T scale = MODE == COL_MUL ? (T)(1.0 / ((double)p->H * (double)p->W)) : (T)1;
     if constexpr (sizeof(T) == 4) {
@@ -1065,15 +1063,17 @@ int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles, int conj_mu
     p->ntile = ntiles;
     const size_t off = (size_t)tile_lo * tile_elems;
     if (MODE == COL_MUL) return col_stage<T, COL_MUL>(p, 1, (const cx<T>*)p->eK + off, nullptr, nullptr, conj_mult, scale, no_loss());
-    return col_stage<T, COL_RES2>(p, 1, (const cx<T>*)p->eK + off, (const T*)p->G + off, nullptr, 0, (T)1, no_loss());
+    return col_stage<T, COL_RES2>(p, 1, (const cx<T>*)p->eK + off, (const T*)p->G + off, p->injected ? (const cx<T>*)p->Gc + off : nullptr, 0, (T)1, no_loss());
 }
 
 // Chambolle-Pock row step (cp:58-92) on the local rows; one half-spectrum, laid out [tile][rows][C].
 template <typename T>
-int slab_rows_cp_impl(ddn_plan* p, int rows, void* spec, void* x, void* z, void* y, const void* b, double t, double s, double gamma,
+int slab_rows_cp_impl(ddn_plan* p, int rows, void* spec, void* spec_aux, void* x, void* z, void* y, const void* b, double t, double s, double gamma,
                       int objective, int step, int consume, int produce) {
     if (!p->have_K) return fail(DDN_E_STATE, "slab_rows_cp: operators not set");
-    if (p->injected) return fail(DDN_E_UNSUPPORTED, "slab_rows_cp: injected eigen arrays are not supported");
+    // injected eigen arrays: D^T y travels from the dual-step launch to the primal-step launch of the same
+    // rows as a spectrum of its own, which never passes through the column stage
+    if (p->injected && !spec_aux) return fail(DDN_E_ARG, "slab_rows_cp: injected eigen arrays need spec_aux_dev");
     SlabRows guard(p, rows);
     const size_t plane = (size_t)rows * p->W;
     RowCfg cfg;
@@ -1087,7 +1087,7 @@ int slab_rows_cp_impl(ddn_plan* p, int rows, void* spec, void* x, void* z, void*
     RowCommon<T> c = row_common<T>(p, cfg.V, consume != 0, produce != 0);
     c.stop = nullptr;
     c.S0 = (cx<T>*)spec;
-    c.S1 = nullptr;
+    c.S1 = (cx<T>*)spec_aux;
     c.lay.H = rows;
     c.nyqd = nullptr;
     c.ilv = 0;
@@ -1388,15 +1388,15 @@ int ddn_slab_cols_multiply(ddn_plan* p, void* spec_cols, int tile_lo, int n_tile
     return slab_cols_impl<double, COL_MUL>(p, spec_cols, tile_lo, n_tiles_local, conj ? 1 : 0);
 }
 
-int ddn_slab_rows_cp(ddn_plan* p, int rows, void* spec_rows, void* x, void* z, void* y, const void* b, double t, double s, double gamma,
+int ddn_slab_rows_cp(ddn_plan* p, int rows, void* spec_rows, void* spec_aux, void* x, void* z, void* y, const void* b, double t, double s, double gamma,
                      int objective, int step, int consume, int produce) {
     if (!p || !spec_rows || !x || !z || !y || !b) return fail(DDN_E_ARG, "slab_rows_cp: null argument");
     if (objective != DDN_OBJ_L1 && objective != DDN_OBJ_L2) return fail(DDN_E_ARG, "Invalid objective function. Choose 'l1' or 'l2'.");
     if (p->batch != 1) return fail(DDN_E_ARG, "slab_rows_cp: the plan must hold one image");
     if (rows < 1 || rows > p->H) return fail(DDN_E_ARG, "slab_rows_cp: bad row count");
     if (p->tile_pad_rows) return fail(DDN_E_UNSUPPORTED, "slab_rows_cp: padded tiles are not supported");
-    if (p->dtype == DDN_F32) return slab_rows_cp_impl<float>(p, rows, spec_rows, x, z, y, b, t, s, gamma, objective, step, consume, produce);
-    return slab_rows_cp_impl<double>(p, rows, spec_rows, x, z, y, b, t, s, gamma, objective, step, consume, produce);
+    if (p->dtype == DDN_F32) return slab_rows_cp_impl<float>(p, rows, spec_rows, spec_aux, x, z, y, b, t, s, gamma, objective, step, consume, produce);
+    return slab_rows_cp_impl<double>(p, rows, spec_rows, spec_aux, x, z, y, b, t, s, gamma, objective, step, consume, produce);
 }
 
 int ddn_slab_loss(ddn_plan* p, int rows, double* record8) {

@@ -130,7 +130,7 @@ class SlabSolver:
     """Plan, buffers and the two local stages of one slab-decomposed solve (fp32 or fp64)."""
 
     def __init__(self, kernel, image_shape: Tuple[int, int], t_resolvent: float, s_resolvent: float, dtype=torch.float32, device=None, group=None,
-                 n_spectra: int = 2):
+                 n_spectra: int = 2, eig_arrays=None):
         from . import _lib as L
         from .plan import Plan, compute_device, real_dtype
         self.L = L
@@ -140,9 +140,16 @@ class SlabSolver:
         self.dt = real_dtype(dtype)
         self.dev = compute_device(device)
         self.plan = Plan(H, W, 1, self.dt, self.dev)
-        self.plan.set_kernel(kernel)
         # eig_vals_mat = 1 + t^2 |eK|^2 + (t^2 + t s) |eD|^2   (multiplying_matrix.py:61-72 with D1 == D2)
-        self.plan.set_resolvent(float(t_resolvent) ** 2, float(t_resolvent) ** 2 + float(t_resolvent) * float(s_resolvent))
+        cK, cD = float(t_resolvent) ** 2, float(t_resolvent) ** 2 + float(t_resolvent) * float(s_resolvent)
+        if eig_arrays is not None:
+            # the reference's own eigen arrays of the WHOLE image, consumed bit for bit (fp64 parity)
+            self.plan.set_eig(eig_arrays["K"], eig_arrays.get("D"))
+            self.plan.set_resolvent(cK, cD, eig_arrays["M"])
+        else:
+            self.plan.set_kernel(kernel)
+            self.plan.set_resolvent(cK, cD)
+        self.injected = eig_arrays is not None
         c, n = C.c_int(0), C.c_int(0)
         L.check(L.lib().ddn_slab_layout(self.plan._h, C.byref(c), C.byref(n)))
         self.lay = SlabLayout(H, W, c.value, n.value, self.rank, self.world)
@@ -168,7 +175,10 @@ class SlabSolver:
 
     def rows_cp(self, state, b: torch.Tensor, t: float, s: float, gamma: float, objective: int, step: int, consume: bool, produce: bool):
         from .plan import _ptr
-        self.L.check(self.L.lib().ddn_slab_rows_cp(self.plan._h, self.lay.rows, _ptr(self.xch.spec_rows), _ptr(state[0]), _ptr(state[1]), _ptr(state[2]), _ptr(b),
+        if self.injected and getattr(self, "_aux", None) is None:
+            self._aux = torch.zeros_like(self.xch.spec_rows)
+        aux = self._aux if self.injected else None
+        self.L.check(self.L.lib().ddn_slab_rows_cp(self.plan._h, self.lay.rows, _ptr(self.xch.spec_rows), _ptr(aux), _ptr(state[0]), _ptr(state[1]), _ptr(state[2]), _ptr(b),
                                                    float(t), float(s), float(gamma), int(objective), int(step), int(consume), int(produce)))
 
     def column_multiply(self, conj: bool):
@@ -197,14 +207,16 @@ def admm_solver_slab(b_rows: torch.Tensor, image_shape: Tuple[int, int], objecti
     Keyword extensions: init_state = (u, w, y, z) local slabs ((rows, W) and (3, rows, W)); without it
     the reference's draws (admm:49-54) are made for the WHOLE image on every rank from torch's CPU
     generator and the local rows kept, so that all ranks must share the generator state;
-    return_state, return_losses (records of the whole image: list of dicts l1_loss, l2_loss, mse,
-    psnr per recorded iteration), dtype, device, group."""
+    return_state, return_losses (records of the whole image, [iterations][8]: l1, l2, mse, psnr of the
+    primary pair, then of the secondary pair), eig_arrays = {"K", "D", "M"} (the reference's eigen arrays
+    of the whole image, for fp64 parity), dtype, device, group."""
     if objective_function not in ("l1", "l2"):
         raise ValueError("Invalid objective function. Choose 'l1' or 'l2'.")
     from . import _lib as L
     from .plan import stage
     H, W = int(image_shape[0]), int(image_shape[1])
-    sv = SlabSolver(kernel, (H, W), 1, 1, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"))
+    sv = SlabSolver(kernel, (H, W), 1, 1, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
+                    eig_arrays=kwargs.get("eig_arrays"))
     try:
         lay, dev, dt = sv.lay, sv.dev, sv.dt
         if tuple(b_rows.shape) != (lay.rows, W):
@@ -261,7 +273,8 @@ def primal_dr_splitting_slab(problem: str, kernel, b_rows: torch.Tensor, image_s
     from .plan import stage
     from .core.proximal_operators import prox_box
     H, W = int(image_shape[0]), int(image_shape[1])
-    sv = SlabSolver(kernel, (H, W), t, t, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"))
+    sv = SlabSolver(kernel, (H, W), t, t, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
+                    eig_arrays=kwargs.get("eig_arrays"))
     try:
         dev, dt = sv.dev, sv.dt
         bd = stage(b_rows, dev, dt)
@@ -295,7 +308,8 @@ def primal_dual_dr_splitting_slab(b_rows: torch.Tensor, kernel, image_shape: Tup
     from .plan import stage
     from .core.proximal_operators import prox_box
     H, W = int(image_shape[0]), int(image_shape[1])
-    sv = SlabSolver(kernel, (H, W), t, t, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"))
+    sv = SlabSolver(kernel, (H, W), t, t, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
+                    eig_arrays=kwargs.get("eig_arrays"))
     try:
         lay, dev, dt = sv.lay, sv.dev, sv.dt
         bd = stage(b_rows, dev, dt)
@@ -333,7 +347,7 @@ def chambolle_pock_slab(b_rows: torch.Tensor, kernel, image_shape: Tuple[int, in
     from .plan import stage
     H, W = int(image_shape[0]), int(image_shape[1])
     sv = SlabSolver(kernel, (H, W), 1, 1, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
-                    n_spectra=1)
+                    n_spectra=1, eig_arrays=kwargs.get("eig_arrays"))
     try:
         lay, dev, dt = sv.lay, sv.dev, sv.dt
         b2 = b_rows.reshape(lay.rows, W)

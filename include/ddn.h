@@ -205,7 +205,8 @@ int ddn_pddr_run(ddn_plan* p, void* p_dev, void* q_dev, const void* b_dev,
  *                   the LOCAL rows seen by the last consuming ddn_slab_rows launch; l1 and l2^2
  *                   add up over ranks (mse and psnr are per-slab figures over the full pixel count).
  * The exchange between the two buffers is an all-to-all owned by the caller (RCCL through
- * torch.distributed in this package).  No early stop inside these calls. */
+ * torch.distributed in this package).  No early stop inside these calls.  Injected eigen arrays
+ * (ddn_plan_set_eig, ddn_plan_set_resolvent with M_dev: the fp64 parity route) are honoured. */
 int ddn_slab_layout(ddn_plan* p, int* tile_cols, int* n_tiles);
 int ddn_slab_rows(ddn_plan* p, int solver, int rows, void* spec_rows_dev, void* s0_dev, void* s1_dev, void* s2_dev, void* s3_dev,
                   const void* b_dev, double t, double rho, double gamma, int objective, int consume, int produce,
@@ -219,9 +220,12 @@ int ddn_slab_loss(ddn_plan* p, int rows, double* record8_dev);
  *                           A loop is: (step 1, consume 0, produce 1), then per iteration
  *                           cols_multiply(conj 0), (step 0, 1, 1), cols_multiply(conj 1), (step 1, 1, produce
  *                           unless last); ddn_slab_loss after a consuming step-1 launch gives (x_next, b).
+ *                           spec_aux_dev: a second buffer shaped like spec_rows, needed only with injected eigen
+ *                           arrays (ddn_plan_set_eig), where D^T y passes from the dual-step launch to the
+ *                           primal-step launch as a spectrum that never leaves the rank; else NULL.
  *   ddn_slab_cols_multiply  spectrum <- eK (conj = 0) or conj(eK) (conj = 1) times spectrum / (H W), between a
  *                           forward and an inverse column transform, on the local tile range. */
-int ddn_slab_rows_cp(ddn_plan* p, int rows, void* spec_rows_dev, void* x_dev, void* z_dev, void* y_dev, const void* b_dev,
+int ddn_slab_rows_cp(ddn_plan* p, int rows, void* spec_rows_dev, void* spec_aux_dev, void* x_dev, void* z_dev, void* y_dev, const void* b_dev,
                      double t, double s, double gamma, int objective, int step, int consume, int produce);
 int ddn_slab_cols_multiply(ddn_plan* p, void* spec_cols_dev, int tile_lo, int n_tiles_local, int conj);
 

@@ -156,3 +156,60 @@ def test_two_ranks_share_one_image(H, W, kname, dtname):
                 assert v < 2e-5, (r, name, v)
             else:
                 assert v < tol, (r, name, v)
+
+
+# ------------------------------------------------------------------ against the reference's own iterates
+def _t(a, dt):
+    return torch.from_numpy(np.asarray(a)).to(dt)
+
+
+def _golden_worker(rank, world, port, fname, dtname, Ns, out):
+    import torch.distributed as dist
+    import convex_optimization_amd.slab as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dt = getattr(torch, dtname)
+        g = np.load(os.path.join(GOLDEN, fname))
+        b = _t(g["b"], dt); kern = g["kernel"]
+        H, W = b.shape
+        rows = H // world
+        sl = slice(rank * rows, (rank + 1) * rows)
+        f64 = dtname == "float64"
+        ea1 = {"K": g["eigK"], "D": g["eigD"], "M": g["M_t1_s1"]} if f64 else None
+        ea2 = {"K": g["eigK"], "D": g["eigD"], "M": g["M_pdr_t2"]} if f64 else None
+        ea3 = {"K": g["eigK"], "D": g["eigD"], "M": g["M_pddr_t3"]} if f64 else None
+        cut = lambda names: [_t(g[n], dt)[..., sl, :] for n in names]
+        res = {}
+        for N in Ns:
+            x = S.chambolle_pock_slab(b[sl], kern, (H, W), t=0.3, s=0.3, max_iter=N + 1, init_state=cut(["cp_x0", "cp_z0", "cp_y0"]), eig_arrays=ea1)
+            res[f"cp_{N}"] = rel(x.numpy(), g[f"cpstab_l1_N{N}"][..., sl, :])
+            for obj in ("l1", "l2"):
+                x = S.admm_solver_slab(b[sl], (H, W), obj, kernel=kern, niters=N + 1, init_state=cut(["admm_u0", "admm_w0", "admm_y0", "admm_z0"]), eig_arrays=ea1)
+                res[f"admm_{obj}_{N}"] = rel(x.numpy(), g[f"admm_{obj}_N{N}"][sl])
+                x = S.primal_dr_splitting_slab(obj, kern, b[sl], (H, W), niters=N, eig_arrays=ea2)
+                res[f"pdr_{obj}_{N}"] = rel(x.numpy(), g[f"pdr_{obj}_N{N}"][sl])
+            x = S.primal_dual_dr_splitting_slab(b[sl], kern, (H, W), niters=N + 1, init_state=cut(["pddr_p0", "pddr_q0"]), eig_arrays=ea3)
+            res[f"pddr_{N}"] = rel(x.numpy(), g[f"pddr_N{N}"][sl])
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fname,dtname,tol", [("traj_f32_gauss9_64x64.npz", "float32", 1e-5), ("traj_f32_motion15_45_64x64.npz", "float32", 1e-5),
+                                              ("traj_f64_gauss9_64x64.npz", "float64", 1e-11), ("traj_f64_motion15_45_64x64.npz", "float64", 1e-11)])
+def test_two_ranks_vs_reference_iterates(fname, dtname, tol):
+    """Two ranks sharing one 64 x 64 image against the iterates the reference itself produced (golden
+    fixtures): all four solvers, N = 5 / 20 / 100; fp64 with the reference's complex64-valued eigen
+    arrays consumed bit for bit (relative L2 <= 1e-11), fp32 <= 1e-5."""
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_golden_worker, args=(world, _free_port(), fname, dtname, [5, 20, 100], out), nprocs=world, join=True)
+    for r in range(world):
+        res = dict(out[r])
+        bad = {k: v for k, v in res.items() if not v < tol}
+        assert not bad, (r, bad)

@@ -58,10 +58,10 @@ def lib():
         "ddn_plan_enable_timing": [vp, i],
         "ddn_slab_layout": [vp, C.POINTER(i), C.POINTER(i)],
         "ddn_slab_rows": [vp, i, i, vp, vp, vp, vp, vp, vp, d, d, d, i, i, i, vp, i],
-        "ddn_slab_cols": [vp, vp, i, i],
+        "ddn_slab_cols": [vp, vp, i, i, i],
         "ddn_slab_loss": [vp, i, vp],
         "ddn_slab_rows_cp": [vp, i, vp, vp, vp, vp, vp, vp, d, d, d, i, i, i, i],
-        "ddn_slab_cols_multiply": [vp, vp, i, i, i],
+        "ddn_slab_cols_multiply": [vp, vp, i, i, i, i],
         "ddn_plan_last_timing": [vp, C.POINTER(d), C.POINTER(d), C.POINTER(i), C.POINTER(i)],
     }
     for name, args in sigs.items():

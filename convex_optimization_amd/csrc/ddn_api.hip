@@ -176,6 +176,9 @@ struct ddn_plan {
     int* stop = nullptr;         // [batch]
     bool have_K = false, have_G = false, injected = false;
     bool slab_cols = false;      // a column stage over a tile range of a row-slab decomposition: tile-generic kernels only
+    int slab_pitch = 0;          // while slab_cols: tile pitch (rows) of the spectral buffers when it is not H
+    int rb_shift = 0;            // while slab_cols: rows stored in per-source blocks of 1 << rb_shift rows,
+    long long rb_extra = 0;      //   block i displaced by i * rb_extra rows (see ColArgs)
     long long* dbg = nullptr;    // diagnostic phase stamps (DDN_DEBUG_STAMPS=1), 16 per workgroup
     // timing
     bool timing = false;
@@ -195,7 +198,7 @@ size_t col_lds_bytes(int n, int cshift, int narr) {
 
 SpecLayout layout_of(const ddn_plan* p) {
     SpecLayout l;
-    l.H = p->H + p->tile_pad_rows;  // row pitch of a tile (rows beyond H are padding)
+    l.H = p->slab_pitch ? p->slab_pitch : p->H + p->tile_pad_rows;  // row pitch of a tile (rows beyond H are padding)
     l.cs = p->cs;
     l.ntile = p->ntile;
     return l;
@@ -467,6 +470,11 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
     a.conj_mult = conj_mult;
     a.scale = scale;
     a.lf = no_loss();
+    if (p->slab_pitch) {
+        a.mult_pitch = p->H + p->tile_pad_rows;
+        a.rb_shift = p->rb_shift;
+        a.rb_extra = p->rb_extra;
+    }
     const int cs = p->cs;
     if (p->A == 1) {
         a.fd = p->fb;
@@ -1021,26 +1029,50 @@ int slab_rows_impl(ddn_plan* p, int solver, int rows, void* spec, void* s0, void
 // Column stage on tiles [tile_lo, tile_lo + ntiles) of the image's half-spectra: MODE COL_RES2 (the
 // resolvent solvers; spec holds both spectra) or COL_MUL (Chambolle-Pock: one spectrum times eK or conj(eK)).
 template <typename T, int MODE>
-int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles, int conj_mult) {
+int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles, int conj_mult, int nblocks) {
     if (!p->have_K || (MODE == COL_RES2 && !p->have_G)) return fail(DDN_E_STATE, "slab_cols: operators not set");
     if (ntiles == 0) return DDN_OK;
+    constexpr int NS = MODE == COL_RES2 ? 2 : 1;
     const T scale = MODE == COL_MUL ? (T)(1.0 / ((double)p->H * (double)p->W)) : (T)1;
+    const size_t C = (size_t)1 << p->cs;
+    // nblocks = 0: spec is [spectrum][tile][H][C].  nblocks = P >= 1: spec is [source rank][tile][spectrum][H / P][C],
+    // what an all-to-all of the ranks' row-side buffers delivers; the kernels then address a tile with pitch
+    // NS * rows, find the second spectrum rows * C elements after the first, and displace the rows of source
+    // rank i by i * (ntiles * NS - 1) * rows rows.
+    int pitch = 0, sh = 0;
+    long long extra_rows = 0;
+    size_t s1_off = (size_t)ntiles * ((size_t)p->H << p->cs);
+    if (nblocks >= 1) {
+        if (p->H % nblocks) return fail(DDN_E_ARG, "slab_cols: H is not a multiple of the number of row blocks");
+        const int rows = p->H / nblocks;
+        pitch = NS * rows;
+        s1_off = (size_t)rows * C;
+        extra_rows = nblocks > 1 ? (long long)rows * (ntiles * NS - 1) : 0;
+        if (extra_rows) {
+            if (rows & (rows - 1)) return fail(DDN_E_UNSUPPORTED, "slab_cols: rows per block must be a power of two");
+            while ((1 << sh) < rows) ++sh;
+        }
+    }
     if constexpr (sizeof(T) == 4) {
         // H = 4096 / 512-2048: the register-resident column kernels, pointed at the local columns (their
         // multipliers are column-major, so a column range is a pointer offset; column W/2 stays in its tile)
         const bool wave1 = wcol_ready(p), waven = !wave1 && wcoln_ready(p);
-        if ((wave1 || waven) && (MODE == COL_MUL || p->Gcm_ok) && p->cs > 2) {
+        if ((wave1 || waven) && (MODE == COL_MUL || p->Gcm_ok) && p->cs > 2 && (!extra_rows || sh >= 6)) {
             const int col_lo = tile_lo << p->cs;
             wcol::Args w;
             std::memset(&w, 0, sizeof(w));
             w.S0 = (cx<float>*)spec;
-            w.S1 = (cx<float>*)spec + (size_t)ntiles * ((size_t)p->H << p->cs);
+            w.S1 = (cx<float>*)spec + s1_off;
             w.eKc = (const cx<float>*)p->eKc + (size_t)col_lo * wcol::kColPitch;
             w.wtw = (const cx<float>*)(wave1 ? p->wtw : p->wtwH);
             w.ed2 = (const float*)p->ed2 + col_lo;
             w.cK = (float)p->g_cK; w.cD = (float)p->g_cD; w.gscale = (float)(1.0 / ((double)p->H * (double)p->W));
             w.lay = layout_of(p);
             w.lay.ntile = ntiles;
+            if (pitch) w.lay.H = pitch;
+            w.Hfft = p->H;
+            w.rb_sh6 = extra_rows ? sh - 6 : 0;
+            w.rb_extra = extra_rows * (long long)C;
             w.Wh = std::min(p->Wh - col_lo, ntiles << p->cs);
             w.batch = 1;
             w.conj_mult = conj_mult;
@@ -1055,12 +1087,15 @@ int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles, int conj_mu
     struct Swap {
         ddn_plan* p; void* S0; void* S1; int ntile;
         explicit Swap(ddn_plan* q) : p(q), S0(q->S0), S1(q->S1), ntile(q->ntile) { p->slab_cols = true; }
-        ~Swap() { p->S0 = S0; p->S1 = S1; p->ntile = ntile; p->slab_cols = false; }
+        ~Swap() { p->S0 = S0; p->S1 = S1; p->ntile = ntile; p->slab_cols = false; p->slab_pitch = 0; p->rb_shift = 0; p->rb_extra = 0; }
     } guard(p);
     const size_t tile_elems = ((size_t)(p->H + p->tile_pad_rows)) << p->cs;
     p->S0 = spec;
-    p->S1 = (cx<T>*)spec + (size_t)ntiles * tile_elems;
+    p->S1 = (cx<T>*)spec + s1_off;
     p->ntile = ntiles;
+    p->slab_pitch = pitch;
+    p->rb_shift = sh;
+    p->rb_extra = extra_rows;
     const size_t off = (size_t)tile_lo * tile_elems;
     if (MODE == COL_MUL) return col_stage<T, COL_MUL>(p, 1, (const cx<T>*)p->eK + off, nullptr, nullptr, conj_mult, scale, no_loss());
     return col_stage<T, COL_RES2>(p, 1, (const cx<T>*)p->eK + off, (const T*)p->G + off, p->injected ? (const cx<T>*)p->Gc + off : nullptr, 0, (T)1, no_loss());
@@ -1370,22 +1405,24 @@ int ddn_slab_rows(ddn_plan* p, int solver, int rows, void* spec_rows, void* s0, 
     return slab_rows_impl<double>(p, solver, rows, spec_rows, s0, s1, s2, s3, b, t, rho, gamma, objective, consume, produce, sol, sol_only);
 }
 
-int ddn_slab_cols(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local) {
+int ddn_slab_cols(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local, int n_row_blocks) {
     if (!p || (!spec_cols && n_tiles_local > 0)) return fail(DDN_E_ARG, "slab_cols: null argument");
     if (p->batch != 1) return fail(DDN_E_ARG, "slab_cols: the plan must hold one image");
     if (tile_lo < 0 || n_tiles_local < 0 || tile_lo + n_tiles_local > p->ntile) return fail(DDN_E_ARG, "slab_cols: bad tile range");
     if (p->tile_pad_rows) return fail(DDN_E_UNSUPPORTED, "slab_cols: padded tiles are not supported");
-    if (p->dtype == DDN_F32) return slab_cols_impl<float, COL_RES2>(p, spec_cols, tile_lo, n_tiles_local, 0);
-    return slab_cols_impl<double, COL_RES2>(p, spec_cols, tile_lo, n_tiles_local, 0);
+    if (n_row_blocks < 0) return fail(DDN_E_ARG, "slab_cols: bad number of row blocks");
+    if (p->dtype == DDN_F32) return slab_cols_impl<float, COL_RES2>(p, spec_cols, tile_lo, n_tiles_local, 0, n_row_blocks);
+    return slab_cols_impl<double, COL_RES2>(p, spec_cols, tile_lo, n_tiles_local, 0, n_row_blocks);
 }
 
-int ddn_slab_cols_multiply(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local, int conj) {
+int ddn_slab_cols_multiply(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local, int conj, int n_row_blocks) {
     if (!p || (!spec_cols && n_tiles_local > 0)) return fail(DDN_E_ARG, "slab_cols_multiply: null argument");
     if (p->batch != 1) return fail(DDN_E_ARG, "slab_cols_multiply: the plan must hold one image");
     if (tile_lo < 0 || n_tiles_local < 0 || tile_lo + n_tiles_local > p->ntile) return fail(DDN_E_ARG, "slab_cols_multiply: bad tile range");
     if (p->tile_pad_rows) return fail(DDN_E_UNSUPPORTED, "slab_cols_multiply: padded tiles are not supported");
-    if (p->dtype == DDN_F32) return slab_cols_impl<float, COL_MUL>(p, spec_cols, tile_lo, n_tiles_local, conj ? 1 : 0);
-    return slab_cols_impl<double, COL_MUL>(p, spec_cols, tile_lo, n_tiles_local, conj ? 1 : 0);
+    if (n_row_blocks < 0) return fail(DDN_E_ARG, "slab_cols_multiply: bad number of row blocks");
+    if (p->dtype == DDN_F32) return slab_cols_impl<float, COL_MUL>(p, spec_cols, tile_lo, n_tiles_local, conj ? 1 : 0, n_row_blocks);
+    return slab_cols_impl<double, COL_MUL>(p, spec_cols, tile_lo, n_tiles_local, conj ? 1 : 0, n_row_blocks);
 }
 
 int ddn_slab_rows_cp(ddn_plan* p, int rows, void* spec_rows, void* spec_aux, void* x, void* z, void* y, const void* b, double t, double s, double gamma,

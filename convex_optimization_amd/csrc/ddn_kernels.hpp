@@ -300,6 +300,9 @@ struct ColArgs {
     int conj_mult;
     T scale;
     LossFin lf;
+    int mult_pitch;      // tile pitch (rows) of the multiplier arrays when it differs from lay.H (0: the same)
+    int rb_shift;        // rows stored in blocks of 1 << rb_shift rows (one per source rank of a row-slab decomposition):
+    long long rb_extra;  //   row r lives rb_extra * (r >> rb_shift) rows past its place in a plain tile; 0 = plain
 };
 
 template <typename T, int MODE>
@@ -329,8 +332,10 @@ __global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
 
     const Tw<T> tw = tw_setup(twa, a.tw, n, tid, nt);
     const size_t tbase = ((size_t)plane * a.lay.ntile + tile) * a.lay.H;  // in rows
-    const size_t mbase = (size_t)tile * a.lay.H;
+    const size_t mbase = (size_t)tile * (a.mult_pitch ? a.mult_pitch : a.lay.H);
     const int ka = a.outer ? freq_of_pos(a.fa, seg) : 0;
+    // row of the tile -> row of storage
+    auto srow = [&](size_t r) -> size_t { return a.rb_extra ? r + (r >> a.rb_shift) * (size_t)a.rb_extra : r; };
     const int total = n << cs;
     constexpr int UN = 8;  // loads in flight per thread and array
     for (int i0 = tid; i0 < total; i0 += nt * UN) {
@@ -340,7 +345,7 @@ __global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
             const int i = i0 + u * nt;
             if (i < total) {
                 const int c = i & (C - 1), e = i >> cs;
-                const size_t g = ((tbase + (size_t)seg * a.seg_stride + (size_t)e * a.row_stride) << cs) + c;
+                const size_t g = ((tbase + srow((size_t)seg * a.seg_stride + (size_t)e * a.row_stride)) << cs) + c;
                 v0[u] = a.S0[g];
                 if (NARR == 2) v1[u] = a.S1[g];
                 if (a.outer & 1) w[u] = a.twH[e * ka];
@@ -406,7 +411,7 @@ __global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
     }
     for (int i = tid; i < total; i += nt) {
         const int c = i & (C - 1), e = i >> cs;
-        const size_t g = ((tbase + (size_t)seg * a.seg_stride + (size_t)e * a.row_stride) << cs) + c;
+        const size_t g = ((tbase + srow((size_t)seg * a.seg_stride + (size_t)e * a.row_stride)) << cs) + c;
         cx<T> v0 = lds[SW(i)];
         cx<T> v1;
         if (NARR == 2) v1 = lds[arr + SW(i)];

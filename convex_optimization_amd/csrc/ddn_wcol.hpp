@@ -32,14 +32,17 @@ constexpr size_t kLdsExtra = 2 * 64 * sizeof(cx<float>);          // lane-0 tabl
 // Row-major global <-> column-owner registers for one quarter tile (4 columns), executed by the
 // four waves wq = 0..3 of a half; wave wq ends up with column wq: lane l, register r = row 64 r + l.
 // base: the array offset to (row 0, first column of the quarter); rpitch = elements per row (tile width).
-__device__ __forceinline__ void load_quarter(cx<float> (&d)[64], const cx<float>* base, int rpitch, cx<float>* stg, int wq, int lane, bool active, int dbg_mode = 0) {
+template <bool RB = false>
+__device__ __forceinline__ void load_quarter(cx<float> (&d)[64], const cx<float>* base, int rpitch, cx<float>* stg, int wq, int lane, bool active, int dbg_mode = 0,
+                                             int rbsh = 0, size_t rbx = 0) {
     const int rl = 16 * wq + (lane >> 2), cl = lane & 3;
     const unsigned goff = (unsigned)(rl * rpitch + cl);
     const int wr = 4 * rl + cl + (rl >> 2);
     const int rd = 4 * lane + wq + (lane >> 2);
     // every global load of the column is issued before the first use: 64 x 512 bytes in flight per wave
 #pragma unroll
-    for (int r = 0; r < 64; ++r) d[r] = active ? (base + (size_t)((dbg_mode & 4) ? 0 : ((dbg_mode & 8) ? 16 * r : 64 * r)) * rpitch)[goff] : mk<float>(0.f, 0.f);
+    for (int r = 0; r < 64; ++r)
+        d[r] = active ? (base + (size_t)((dbg_mode & 4) ? 0 : ((dbg_mode & 8) ? 16 * r : 64 * r)) * rpitch + (RB ? (size_t)(r >> rbsh) * rbx : (size_t)0))[goff] : mk<float>(0.f, 0.f);
     sched_fence();
 #pragma unroll
     for (int round = 0; round < 64 / kSlabs; ++round) {
@@ -51,7 +54,9 @@ __device__ __forceinline__ void load_quarter(cx<float> (&d)[64], const cx<float>
         __syncthreads();
     }
 }
-__device__ __forceinline__ void store_quarter(const cx<float> (&d)[64], cx<float>* base, int rpitch, cx<float>* stg, int wq, int lane, bool active, int ncols) {
+template <bool RB = false>
+__device__ __forceinline__ void store_quarter(const cx<float> (&d)[64], cx<float>* base, int rpitch, cx<float>* stg, int wq, int lane, bool active, int ncols,
+                                              int rbsh = 0, size_t rbx = 0) {
     const int rl = 16 * wq + (lane >> 2), cl = lane & 3;
     const unsigned goff = (unsigned)(rl * rpitch + cl);
     const int wr = 4 * rl + cl + (rl >> 2);
@@ -68,7 +73,7 @@ __device__ __forceinline__ void store_quarter(const cx<float> (&d)[64], cx<float
 #pragma unroll
             for (int s = 0; s < kSlabs; ++s) {
                 const size_t row0 = (size_t)(64 * (round * kSlabs + s));
-                (base + row0 * rpitch)[goff] = tmp[s];
+                (base + row0 * rpitch + (RB ? (size_t)((round * kSlabs + s) >> rbsh) * rbx : (size_t)0))[goff] = tmp[s];
             }
         }
         __syncthreads();
@@ -267,9 +272,10 @@ __device__ __forceinline__ void mul_packed(cx<float> (&d)[64], const cx<float>* 
 }
 
 // MODE: COL_RES2 (eight waves: four columns of S0 and of S1) or COL_MUL (four waves: four columns of S0)
-template <int MODE, bool PACKED, bool ILV = false>
+template <int MODE, bool PACKED, bool ILV = false, bool RB = false>
 __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Args a) {
     static_assert(!ILV || (MODE == COL_RES2 && !PACKED), "interleaved spectra: resolvent mode, plain columns");
+    static_assert(!RB || (!ILV && !PACKED), "row blocks: plain columns, separate spectra");
     extern __shared__ __align__(16) float tiles[];
     constexpr int NT = MODE == COL_RES2 ? 512 : 256;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -333,7 +339,7 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
         const cx<float>* const colp = Sarr + qbase + wq;
 #pragma unroll
         for (int r = 0; r < 64; ++r) d[r] = (colp + ((size_t)(64 * r) << cs))[(unsigned)lane << cs];
-    } else load_quarter(d, Sarr + qbase, C, stg, wq, lane, true, a.dbg_mode);
+    } else load_quarter<RB>(d, Sarr + qbase, C, stg, wq, lane, true, a.dbg_mode, a.rb_sh6, (size_t)a.rb_extra);
     if (packed) {
         const unsigned noff = (unsigned)(lane << cs);
 #pragma unroll
@@ -417,7 +423,7 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
 #pragma unroll
             for (int r = 0; r < 64; ++r) (colp + (size_t)(64 * r) * 4)[(unsigned)lane * 4u] = d[r];
         }
-    } else store_quarter(d, Sarr + opaque(qbase), C, stg, wq, lane, true, ncols);
+    } else store_quarter<RB>(d, Sarr + opaque(qbase), C, stg, wq, lane, true, ncols, a.rb_sh6, (size_t)a.rb_extra);
     if (packed) {
         const unsigned noff = (unsigned)(lane << cs);
         cx<float>* const ncolp = Sarr + opaque(nbase);

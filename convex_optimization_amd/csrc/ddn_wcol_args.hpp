@@ -26,6 +26,9 @@ struct Args {
     LossFin lf;
     long long* dbg;        // diagnostic: per-workgroup phase stamps (16 per workgroup) or null
     int ilv;               // resolvent mode: S0 holds the (S0, S1) pairs interleaved element by element
+    int Hfft;              // transform length when lay.H is only a pitch (0: lay.H is both)
+    int rb_sh6;            // rows stored in blocks of 64 << rb_sh6 rows (one block per source rank of a row-slab
+    long long rb_extra;    //   decomposition): block i starts i * rb_extra elements past its place in a plain tile; 0 = plain
     int dbg_mode;          // diagnostic ablations (results wrong by construction): bit0 no multiplier loads, bit1 no exchange, bit2 every slab reads slab 0
 };
 

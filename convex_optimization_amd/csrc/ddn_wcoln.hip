@@ -3,13 +3,13 @@
 #include "ddn_launch.hpp"
 #include "ddn_wcoln.hpp"
 
-template <int MODE, int R, int NP, bool ILV = false>
+template <int MODE, int R, int NP, bool ILV = false, bool RB = false>
 static int wcoln_go1(hipStream_t st, const wcol::Args& a) {
     constexpr int waves = (MODE == COL_RES2 ? 2 : 1) * NP;
     constexpr int M = 64 / R;
     if ((1 << a.lay.cs) < M * NP || a.lay.cs > 4) return DDN_E_UNSUPPORTED;
     const int G = (1 << a.lay.cs) / (M * NP);
-    auto fn = wcol::k_wave_colN<MODE, R, NP, ILV>;
+    auto fn = wcol::k_wave_colN<MODE, R, NP, ILV, RB>;
     int rc = ensure_lds_attr((const void*)fn);
     if (rc) return rc;
     const int grid = a.batch * 8 * G * ((a.lay.ntile + 7) / 8);
@@ -24,6 +24,11 @@ static int wcoln_go(hipStream_t st, const wcol::Args& a) {
     // H = 2048 (16 bytes of a line per group).  DDN_COLN_NP overrides, for measurements.
     static const int np = getenv("DDN_COLN_NP") ? atoi(getenv("DDN_COLN_NP")) : (R == 32 ? 2 : 1);
     constexpr int M = 64 / R;
+    if (a.rb_extra) {
+        // rows stored in per-source blocks (row-slab decomposition): separate spectra, one group per workgroup
+        if (a.ilv) return DDN_E_UNSUPPORTED;
+        return wcoln_go1<MODE, R, 1, false, true>(st, a);
+    }
     if constexpr (MODE == COL_RES2) {
         if (a.ilv) {
             if (np >= 2 && (1 << a.lay.cs) >= 2 * M) return wcoln_go1<MODE, R, 2, true>(st, a);
@@ -37,7 +42,7 @@ static int wcoln_go(hipStream_t st, const wcol::Args& a) {
 
 int wcoln_launch(hipStream_t st, int mode, const wcol::Args& a) {
     const bool res = mode == COL_RES2;
-    switch (a.lay.H) {
+    switch (a.Hfft ? a.Hfft : a.lay.H) {
         case 512: return res ? wcoln_go<COL_RES2, 8>(st, a) : wcoln_go<COL_MUL, 8>(st, a);
         case 1024: return res ? wcoln_go<COL_RES2, 16>(st, a) : wcoln_go<COL_MUL, 16>(st, a);
         case 2048: return res ? wcoln_go<COL_RES2, 32>(st, a) : wcoln_go<COL_MUL, 32>(st, a);

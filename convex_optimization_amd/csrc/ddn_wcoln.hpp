@@ -57,9 +57,10 @@ __device__ __forceinline__ void res2_pairN(cx<float> (&d)[64], const cx<float>* 
 // both spectra are 16 M contiguous bytes of a row.  Each wave of a pair then loads whole pairs for
 // half of the rows (wave 0 the first R / 2 slabs of 64 rows, wave 1 the rest) and the two swap the
 // halves they loaded for each other through their tiles; the store mirrors it.
-template <int MODE, int R, int NP, bool ILV = false>
+template <int MODE, int R, int NP, bool ILV = false, bool RB = false>
 __global__ void __launch_bounds__((MODE == COL_RES2 ? 128 : 64) * NP, 2) k_wave_colN(Args a) {
     static_assert(!ILV || MODE == COL_RES2, "interleaved spectra: resolvent mode only");
+    static_assert(!RB || !ILV, "row blocks: separate spectra");
     constexpr int M = 64 / R;       // columns per wave
     constexpr int LM = M == 2 ? 1 : (M == 4 ? 2 : 3);
     constexpr int NT = (MODE == COL_RES2 ? 128 : 64) * NP;
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__((MODE == COL_RES2 ? 128 : 64) * NP, 2) k_wave_
     } else {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            const f4* const p = reinterpret_cast<const f4*>(Sarr + gbase + ((size_t)(64 * j) << cs));
+            const f4* const p = reinterpret_cast<const f4*>(Sarr + gbase + ((size_t)(64 * j) << cs) + (RB ? (size_t)(j >> a.rb_sh6) * (size_t)a.rb_extra : (size_t)0));
 #pragma unroll
             for (int q2 = 0; q2 < M / 2; ++q2) {
                 const f4 v = (p + q2)[loff >> 1];
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__((MODE == COL_RES2 ? 128 : 64) * NP, 2) k_wave_
         cx<float>* const Sout = Sarr + opaque(gbase);
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            f4* const p = reinterpret_cast<f4*>(Sout + ((size_t)(64 * j) << cs));
+            f4* const p = reinterpret_cast<f4*>(Sout + ((size_t)(64 * j) << cs) + (RB ? (size_t)(j >> a.rb_sh6) * (size_t)a.rb_extra : (size_t)0));
 #pragma unroll
             for (int q2 = 0; q2 < M / 2; ++q2) {
                 f4 v;

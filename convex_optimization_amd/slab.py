@@ -12,10 +12,11 @@ tiles, and afterwards back.  Both redistributions are one all-to-all each (RCCL 
 "nccl" backend; CPU tensors with "gloo" in tests).
 
 Layouts (C = columns per spectral tile, complex elements):
-  row side     [n_tiles][2][rows][C]          the tiles that go to one rank are contiguous
-  column side  [2][local tiles][H][C]         what the column kernel streams
-The all-to-all delivers [source rank][local tiles][2][rows][C]; one strided device copy turns that
-into the column-side layout (and back).
+  row side     [n_tiles][2][rows][C]                    the tiles that go to one rank are contiguous
+  column side  [source rank][local tiles][2][rows][C]   what the all-to-all delivers
+The column kernels address the per-source row blocks of the column side directly (rows per rank a
+power of two), so neither side repacks anything; for other row counts one strided device copy on the
+receiving side builds [2][local tiles][H][C] instead.
 
 Loss records add up over ranks: every rank finalises the sums of its own rows, the sums of |d| and
 d^2 are all-reduced once per solve, and l2 / mse / psnr are recomputed from the totals.  There is
@@ -56,14 +57,29 @@ def _world(group=None) -> Tuple[int, int]:
 
 
 class SlabExchange:
-    """The two spectral buffers of a rank and the all-to-all transposes between them."""
+    """The spectral buffers of a rank and the all-to-all transposes between them.
+
+    blocked (one rank, or a power-of-two number of rows per rank): spec_cols is
+    [source rank][local tiles][spectra][rows][C], exactly what the all-to-all delivers; the column kernels
+    address the per-source row blocks themselves (n_row_blocks = world), so there is no repacking — with one
+    rank spec_cols IS spec_rows.  Otherwise spec_cols is [spectra][local tiles][H][C] and one strided device
+    copy on the receiving side puts every source's rows at their global row index (n_row_blocks = 0)."""
 
     def __init__(self, lay: SlabLayout, complex_dtype: torch.dtype, device, group=None, n_spectra: int = 2):
         self.lay, self.group, self.ns = lay, group, int(n_spectra)
         ns = self.ns
+        self.blocked = lay.world == 1 or (lay.rows & (lay.rows - 1)) == 0
+        self.n_row_blocks = lay.world if self.blocked else 0
         self.spec_rows = torch.zeros((lay.n_tiles, ns, lay.rows, lay.C), dtype=complex_dtype, device=device)
-        self.spec_cols = torch.zeros((ns, lay.local_tiles, lay.H, lay.C), dtype=complex_dtype, device=device)
-        self._stage = torch.zeros((lay.world, lay.local_tiles, ns, lay.rows, lay.C), dtype=complex_dtype, device=device) if lay.world > 1 else None
+        stage = None
+        if lay.world > 1:
+            stage = torch.zeros((lay.world, lay.local_tiles, ns, lay.rows, lay.C), dtype=complex_dtype, device=device)
+        if self.blocked:
+            self.spec_cols = stage if stage is not None else self.spec_rows.unsqueeze(0)
+            self._stage = None
+        else:
+            self.spec_cols = torch.zeros((ns, lay.local_tiles, lay.H, lay.C), dtype=complex_dtype, device=device)
+            self._stage = stage
         per_tile = ns * lay.rows * lay.C * 2  # real numbers per tile of the row-side layout
         self._row_splits = [(hi - lo) * per_tile for lo, hi in lay.tile_spans]
         self._col_splits = [lay.local_tiles * per_tile] * lay.world
@@ -71,9 +87,6 @@ class SlabExchange:
     def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], in_splits: Sequence[int]):
         o = torch.view_as_real(out).reshape(-1)
         i = torch.view_as_real(inp).reshape(-1)
-        if self.lay.world == 1:
-            o.copy_(i)
-            return
         if dist.get_backend(self.group) == "gloo" and o.is_cuda:
             # gloo has no device all-to-all: stage through host memory (tests on a single GPU only)
             oc, ic = torch.empty(o.shape, dtype=o.dtype), i.cpu()
@@ -88,8 +101,10 @@ class SlabExchange:
 
     def rows_to_cols(self):
         """Every rank's rows of my tiles -> spec_cols (all H rows of the local tiles)."""
-        if self.lay.world == 1:  # nothing to exchange: one layout copy
-            self._cols_view().copy_(self.spec_rows.unsqueeze(0).permute(2, 1, 0, 3, 4))
+        if self.lay.world == 1:
+            return  # spec_cols is spec_rows
+        if self.blocked:
+            self._a2a(self.spec_cols, self.spec_rows, self._col_splits, self._row_splits)
             return
         self._a2a(self._stage, self.spec_rows, self._col_splits, self._row_splits)
         self._cols_view().copy_(self._stage.permute(2, 1, 0, 3, 4))
@@ -97,7 +112,9 @@ class SlabExchange:
     def cols_to_rows(self):
         """spec_cols -> my rows of every tile in spec_rows."""
         if self.lay.world == 1:
-            self.spec_rows.unsqueeze(0).copy_(self._cols_view().permute(2, 1, 0, 3, 4))
+            return
+        if self.blocked:
+            self._a2a(self.spec_rows, self.spec_cols, self._row_splits, self._col_splits)
             return
         self._stage.copy_(self._cols_view().permute(2, 1, 0, 3, 4))
         self._a2a(self.spec_rows, self._stage, self._row_splits, self._col_splits)
@@ -170,7 +187,7 @@ class SlabSolver:
         """rows -> columns all-to-all, local column stage, columns -> rows all-to-all."""
         from .plan import _ptr
         self.xch.rows_to_cols()
-        self.L.check(self.L.lib().ddn_slab_cols(self.plan._h, _ptr(self.xch.spec_cols), self.lay.tile_lo, self.lay.local_tiles))
+        self.L.check(self.L.lib().ddn_slab_cols(self.plan._h, _ptr(self.xch.spec_cols), self.lay.tile_lo, self.lay.local_tiles, self.xch.n_row_blocks))
         self.xch.cols_to_rows()
 
     def rows_cp(self, state, b: torch.Tensor, t: float, s: float, gamma: float, objective: int, step: int, consume: bool, produce: bool):
@@ -185,7 +202,8 @@ class SlabSolver:
         """rows -> columns all-to-all, spectrum times eK (or its conjugate) on the local tiles, all-to-all back."""
         from .plan import _ptr
         self.xch.rows_to_cols()
-        self.L.check(self.L.lib().ddn_slab_cols_multiply(self.plan._h, _ptr(self.xch.spec_cols), self.lay.tile_lo, self.lay.local_tiles, int(conj)))
+        self.L.check(self.L.lib().ddn_slab_cols_multiply(self.plan._h, _ptr(self.xch.spec_cols), self.lay.tile_lo, self.lay.local_tiles, int(conj),
+                                                         self.xch.n_row_blocks))
         self.xch.cols_to_rows()
 
     def loss_record(self, out: torch.Tensor):

@@ -199,8 +199,13 @@ int ddn_pddr_run(ddn_plan* p, void* p_dev, void* q_dev, const void* b_dev,
  *                   first half-spectrum, then of the second; the tiles of one destination rank
  *                   are one contiguous block.
  *   ddn_slab_cols   the column stage (forward transform, resolvent algebra, inverse transform) in
- *                   place on spec_cols: complex [2][n_tiles_local][H][C], the tiles
- *                   [tile_lo, tile_lo + n_tiles_local) of both half-spectra with all H rows.
+ *                   place on spec_cols, the tiles [tile_lo, tile_lo + n_tiles_local) of both half-spectra
+ *                   with all H rows.  n_row_blocks = P >= 1: spec_cols is complex
+ *                   [P][n_tiles_local][2][H / P][C] — block i is what rank i's spec_rows holds for these
+ *                   tiles, i.e. exactly what an all-to-all of the spec_rows buffers delivers, so no
+ *                   repacking is needed (with P = 1 spec_cols may be spec_rows itself).  H / P must be a
+ *                   power of two when P > 1 (else DDN_E_UNSUPPORTED).  n_row_blocks = 0: spec_cols is
+ *                   complex [2][n_tiles_local][H][C] (the caller has put the rows in order).
  *   ddn_slab_loss   record8[0..7] = l1, l2, mse, psnr (primary pair), then the secondary pair, of
  *                   the LOCAL rows seen by the last consuming ddn_slab_rows launch; l1 and l2^2
  *                   add up over ranks (mse and psnr are per-slab figures over the full pixel count).
@@ -211,10 +216,11 @@ int ddn_slab_layout(ddn_plan* p, int* tile_cols, int* n_tiles);
 int ddn_slab_rows(ddn_plan* p, int solver, int rows, void* spec_rows_dev, void* s0_dev, void* s1_dev, void* s2_dev, void* s3_dev,
                   const void* b_dev, double t, double rho, double gamma, int objective, int consume, int produce,
                   void* sol_out_dev, int sol_only);
-int ddn_slab_cols(ddn_plan* p, void* spec_cols_dev, int tile_lo, int n_tiles_local);
+int ddn_slab_cols(ddn_plan* p, void* spec_cols_dev, int tile_lo, int n_tiles_local, int n_row_blocks);
 int ddn_slab_loss(ddn_plan* p, int rows, double* record8_dev);
 /* The same for chambolle_pock (cp:58-92), whose iteration has two column stages and one half-spectrum:
- * spec_rows: complex [n_tiles][rows][C]; spec_cols: complex [n_tiles_local][H][C].
+ * spec_rows: complex [n_tiles][rows][C]; spec_cols: complex [P][n_tiles_local][H / P][C] (n_row_blocks = P)
+ * or [n_tiles_local][H][C] (n_row_blocks = 0).
  *   ddn_slab_rows_cp        step = 1: the primal step (consumes K^T y^ ... produces the right-hand side of the
  *                           dual step), step = 0: the dual step; x, z: [rows][W], y: [3][rows][W].
  *                           A loop is: (step 1, consume 0, produce 1), then per iteration
@@ -227,7 +233,7 @@ int ddn_slab_loss(ddn_plan* p, int rows, double* record8_dev);
  *                           forward and an inverse column transform, on the local tile range. */
 int ddn_slab_rows_cp(ddn_plan* p, int rows, void* spec_rows_dev, void* spec_aux_dev, void* x_dev, void* z_dev, void* y_dev, const void* b_dev,
                      double t, double s, double gamma, int objective, int step, int consume, int produce);
-int ddn_slab_cols_multiply(ddn_plan* p, void* spec_cols_dev, int tile_lo, int n_tiles_local, int conj);
+int ddn_slab_cols_multiply(ddn_plan* p, void* spec_cols_dev, int tile_lo, int n_tiles_local, int conj, int n_row_blocks);
 
 /* Timing hook for bench.py: average duration in milliseconds, measured with HIP
  * events on the plan's stream, of the last *_run call's dominant kernel (the fused

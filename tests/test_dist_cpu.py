@@ -93,7 +93,9 @@ def _slab_worker(rank, world, port, H, C, n_tiles, out):
             for lt in range(lay.local_tiles):
                 for h in range(H):
                     for c in range(C):
-                        ok_cols &= complex(x.spec_cols[s, lt, h, c]) == _code(lay.tile_lo + lt, s, h, c)
+                        # blocked: [source rank][tile][spectrum][rows][C] as delivered; else rows put in order
+                        got = x.spec_cols[h // lay.rows, lt, s, h % lay.rows, c] if x.blocked else x.spec_cols[s, lt, h, c]
+                        ok_cols &= complex(got) == _code(lay.tile_lo + lt, s, h, c)
         x.spec_rows.zero_()
         x.cols_to_rows()
         ok_back = torch.equal(x.spec_rows, sent)
@@ -106,7 +108,7 @@ def _slab_worker(rank, world, port, H, C, n_tiles, out):
         tot = combine_loss_records(local, 100.0)
         ok_loss = bool(torch.allclose(tot[:, 0], torch.full((3,), 3.0, dtype=torch.float64)) and torch.allclose(tot[:, 1], torch.full((3,), 5.0, dtype=torch.float64))
                        and torch.allclose(tot[:, 2], torch.full((3,), 0.25, dtype=torch.float64)) and torch.allclose(tot[:, 5], torch.full((3,), 2.0 ** 0.5, dtype=torch.float64)))
-        out[rank] = (bool(ok_cols), bool(ok_back), ok_loss, lay.tile_spans)
+        out[rank] = (bool(ok_cols), bool(ok_back), ok_loss, lay.tile_spans, x.blocked)
     finally:
         dist.destroy_process_group()
 
@@ -120,8 +122,9 @@ def test_world2_gloo_slab_transposes(H, C, n_tiles):
     out = mgr.dict()
     mp.spawn(_slab_worker, args=(world, _free_port(), H, C, n_tiles, out), nprocs=world, join=True)
     for r in range(world):
-        ok_cols, ok_back, ok_loss, spans = out[r]
+        ok_cols, ok_back, ok_loss, spans, blocked = out[r]
         assert ok_cols and ok_back and ok_loss
+        assert blocked == (H // world in (1, 2, 4, 8))   # (8, ...) runs the blocked layout, (6, ...) the repacking one
         assert spans[0][0] == 0 and spans[-1][1] == n_tiles
 
 

@@ -87,8 +87,8 @@ def test_one_rank_slab_path_vs_oracle(H, W, kname, dt):
         ref = _oracle(kern, b, stA, stP, stC, N)
         tol = 1e-5
     else:
-        # fp64 parity with the reference needs its complex64-valued eigen arrays injected, which the slab
-        # path does not take: fp64 is held to the single-GPU path (device-built eigen arrays in double)
+        # without the reference's complex64-valued eigen arrays injected (the golden-trajectory test below does
+        # that) fp64 is held to the single-GPU path, which builds its eigen arrays in double the same way
         import convex_optimization_amd as pkg
         ref = _single_gpu(pkg, kern, b, stA, stP, stC, N)
         tol = 1e-11
@@ -136,11 +136,13 @@ def _two_rank_worker(rank, world, port, H, W, kname, dtname, N, out):
 
 
 @pytest.mark.parametrize("H,W,kname,dtname", [(64, 96, "gauss9", "float32"), (64, 64, "motion15_45", "float64"), (512, 1024, "motion15_45", "float32"),
-                                              (4096, 96, "motion15_45", "float32")])
+                                              (4096, 96, "motion15_45", "float32"), (48, 80, "motion15_45", "float32")])
 def test_two_ranks_share_one_image(H, W, kname, dtname):
     """Two ranks, each owning half of the rows, against the single-GPU solve of the whole image (and the
     oracle at the small sizes): all-to-all both ways around every column stage, uneven tile spans,
-    whole-image loss records from per-slab sums."""
+    whole-image loss records from per-slab sums.  Rows per rank 32 (tile-generic column kernels reading
+    the per-source row blocks), 256 and 2048 (the register-resident column kernels doing the same) and
+    24 (not a power of two: the receiving side repacks)."""
     import torch.multiprocessing as mp
     world, N = 2, 20
     mgr = mp.Manager()

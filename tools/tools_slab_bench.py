@@ -63,7 +63,7 @@ def main():
         sv.xch.rows_to_cols()
         e1 = ev()
         from convex_optimization_amd.plan import _ptr
-        sv.L.check(sv.L.lib().ddn_slab_cols(sv.plan._h, _ptr(sv.xch.spec_cols), sv.lay.tile_lo, sv.lay.local_tiles))
+        sv.L.check(sv.L.lib().ddn_slab_cols(sv.plan._h, _ptr(sv.xch.spec_cols), sv.lay.tile_lo, sv.lay.local_tiles, sv.xch.n_row_blocks))
         e2 = ev()
         sv.xch.cols_to_rows()
         e3 = ev()

@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--solvers", default="chambolle_pock,primal_dr_splitting,primal_dual_dr_splitting,admm_solver")
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--split", type=int, default=0)
@@ -63,11 +63,29 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters in a rehearsal of the multi-rank path on a box with fewer GPUs than
+    # ranks (DDN_BENCH_BACKEND=gloo: RCCL itself refuses two ranks on one device)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("DDN_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+            import faulthandler
+            faulthandler.dump_traceback_later(150, exit=True)   # a rehearsal that hangs names the place and ends
+
+    def allreduce(t, op):
+        # RCCL reduces device tensors in place; the gloo rehearsal goes through host memory
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     import convex_optimization_amd as pkg
     from convex_optimization_amd import _lib as L
@@ -148,7 +166,7 @@ def main():
         run(K, ring)
         if distributed:
             red = ring[:K].clone()
-            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+            allreduce(red, dist.ReduceOp.SUM)
         barrier()
         t1 = time.perf_counter()
         ops.plan.enable_timing(False)
@@ -156,7 +174,7 @@ def main():
         assert int(done.min().item()) == K, f"{name}: only {int(done.min().item())} of {K} iterations ran"
         el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
         if distributed:
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            allreduce(el, dist.ReduceOp.MAX)
         sec = float(el.item())
         total_time += sec
         px = float(B) * H * W

@@ -529,14 +529,20 @@ struct RowCfg {
 template <typename T>
 bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool cp = false) {
     const int W = p->W;
-    if (sizeof(T) == 4 && p->wtwW && !p->injected && p->H % ((cp ? 2 : 1) * (4096 / W)) == 0 && !getenv("DDN_NO_WAVE_ROWS")) {
+    // A wavefront of the register-resident kernels works through its rows alone (two transforms and the pixel
+    // loop in sequence, 35-40 us whatever the image size); with fewer wavefronts than a quarter of the CUs
+    // (half for Chambolle-Pock, whose wavefronts carry twice the rows) the workgroup-per-row LDS kernels
+    // finish sooner (measured at 512 x 512 and 1024 x 1024, one to four images).  DDN_FORCE_WAVE_ROWS=1 overrides.
+    const int wave_items = (W == 4096) ? work_items : p->batch * p->H / ((cp ? 2 : 1) * std::max(1, 4096 / W));
+    const bool wave_pays = wave_items > (cp ? p->num_cu / 2 : p->num_cu / 4) || getenv("DDN_FORCE_WAVE_ROWS");
+    if (sizeof(T) == 4 && p->wtwW && !p->injected && p->H % ((cp ? 2 : 1) * (4096 / W)) == 0 && wave_pays && !getenv("DDN_NO_WAVE_ROWS")) {
         // one wavefront per 4096 / W consecutive rows, twice as many for Chambolle-Pock (ddn_wrown.hpp)
         rc.V = 0; rc.threads = 64; rc.lds = 0;
         const int items = p->batch * p->H / ((cp ? 2 : 1) * (4096 / W));
         rc.grid = std::max(1, std::min(items, p->num_cu * 8));
         return true;
     }
-    if (sizeof(T) == 4 && p->wtw && W == 4096 && !p->injected && !getenv("DDN_NO_WAVE_ROWS")) {
+    if (sizeof(T) == 4 && p->wtw && W == 4096 && !p->injected && wave_pays && !getenv("DDN_NO_WAVE_ROWS")) {
         // one wavefront per row, eight per CU (256 registers each), the row held in registers
         // (four rows per workgroup with 4-column spectral tiles, see ddn_wrow.hpp)
         const int wpw = p->cs == 2 ? 4 : 1;

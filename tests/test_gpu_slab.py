@@ -21,6 +21,13 @@ def rel(a, b):
     return O.rel_l2(np.asarray(a), np.asarray(b))
 
 
+@pytest.fixture(autouse=True)
+def _force_wave_rows(monkeypatch):
+    """Small slabs would get the LDS row kernels by default; these cases are sized to check the
+    register-resident ones too (the spawned ranks inherit the environment)."""
+    monkeypatch.setenv("DDN_FORCE_WAVE_ROWS", "1")
+
+
 def _problem(H, W, kname, dt, noise=0.05):
     k = np.load(os.path.join(GOLDEN, "kernels.npz"))
     kern = torch.from_numpy(k[kname])

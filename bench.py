@@ -159,9 +159,10 @@ def main():
         if Wm > 0:
             run(Wm, ring)
         barrier()
-        # kernel durations are sampled: every 3rd row launch and every 3rd column launch carries HIP events
+        # kernel durations are sampled: every 5th row launch and every 5th column launch carries HIP events (each pair
+        # costs a few microseconds of an iteration that lasts a few hundred)
         # (an odd stride, so that both alternating Chambolle-Pock kernels are sampled)
-        ops.plan.enable_timing(0 if args.no_kernel_timing else 3)
+        ops.plan.enable_timing(0 if args.no_kernel_timing else 5)
         t0 = time.perf_counter()
         run(K, ring)
         if distributed:

@@ -143,13 +143,15 @@ def _two_rank_worker(rank, world, port, H, W, kname, dtname, N, out):
 
 
 @pytest.mark.parametrize("H,W,kname,dtname", [(64, 96, "gauss9", "float32"), (64, 64, "motion15_45", "float64"), (512, 1024, "motion15_45", "float32"),
-                                              (4096, 96, "motion15_45", "float32"), (48, 80, "motion15_45", "float32")])
+                                              (4096, 96, "motion15_45", "float32"), (48, 80, "motion15_45", "float32"),
+                                              (4096, 32, "gauss9", "float64")])
 def test_two_ranks_share_one_image(H, W, kname, dtname):
     """Two ranks, each owning half of the rows, against the single-GPU solve of the whole image (and the
     oracle at the small sizes): all-to-all both ways around every column stage, uneven tile spans,
     whole-image loss records from per-slab sums.  Rows per rank 32 (tile-generic column kernels reading
     the per-source row blocks), 256 and 2048 (the register-resident column kernels doing the same) and
-    24 (not a power of two: the receiving side repacks)."""
+    24 (not a power of two: the receiving side repacks); 4096 x 32 in fp64 runs the three-launch split column
+    transform on the row blocks."""
     import torch.multiprocessing as mp
     world, N = 2, 20
     mgr = mp.Manager()

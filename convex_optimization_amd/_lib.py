@@ -49,6 +49,7 @@ def lib():
         "ddn_circular_convolve2d": [vp, C.POINTER(d), i, i, vp, vp],
         "ddn_prox": [i, i, vp, vp, sz, d, vp],
         "ddn_reduce": [i, vp, vp, sz, i, vp, vp],
+        "ddn_reduce_static": [i, vp, vp, sz, i, vp, vp],
         "ddn_ssim": [i, vp, vp, i, i, i, d, C.POINTER(C.c_float), vp, vp],
         "ddn_apply_x_trans": [i, vp, vp, i, vp, vp],
         "ddn_cp_run": [vp, vp, vp, vp, vp, d, d, d, i, i, vp],
@@ -82,6 +83,6 @@ def check(rc: int):
 
 EXPORTED = ["ddn_version", "ddn_last_error", "ddn_plan_create", "ddn_plan_destroy", "ddn_plan_set_stream", "ddn_plan_tune",
             "ddn_plan_set_kernel", "ddn_plan_set_eig", "ddn_plan_set_resolvent", "ddn_plan_get_eigK", "ddn_apply",
-            "ddn_apply_multiplier", "ddn_circular_convolve2d", "ddn_prox", "ddn_reduce", "ddn_ssim", "ddn_apply_x_trans", "ddn_cp_run", "ddn_admm_run",
+            "ddn_apply_multiplier", "ddn_circular_convolve2d", "ddn_prox", "ddn_reduce", "ddn_reduce_static", "ddn_ssim", "ddn_apply_x_trans", "ddn_cp_run", "ddn_admm_run",
             "ddn_pdr_run", "ddn_pddr_run", "ddn_plan_last_timing", "ddn_plan_enable_timing", "ddn_plan_debug_stamps",
             "ddn_slab_layout", "ddn_slab_rows", "ddn_slab_cols", "ddn_slab_loss", "ddn_slab_rows_cp", "ddn_slab_cols_multiply"]

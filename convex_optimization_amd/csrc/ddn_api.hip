@@ -1137,6 +1137,37 @@ int slab_rows_cp_impl(ddn_plan* p, int rows, void* spec, void* spec_aux, void* x
 
 }  // namespace
 
+// ------------------------------------------------- scratch of the allocation-free entry point
+// ddn_reduce_static keeps its per-chunk partial sums here instead of in a hipMalloc'ed buffer:
+// [image][chunk][2] doubles, 512 KiB, resident on every GPU the library runs on until the process
+// ends.  In host code the array's name is only a handle: the device address comes from
+// hipGetSymbolAddress, once per device, and that pointer is what kernels and copies are given.
+namespace {
+constexpr int kStaticChunks = 256;
+constexpr int kMaxDevices = 64;
+}  // namespace
+static __device__ __align__(256) double scratch[2 * kStaticChunks * DDN_REDUCE_STATIC_MAX_BATCH];
+namespace {
+double* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+
+// device address of `scratch` on the current device (resolved at the first call on that device)
+int static_scratch(double** out) {
+    int dev = -1;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(DDN_E_UNSUPPORTED, "static scratch: device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return fail(DDN_E_HIP, e != hipSuccess ? hipGetErrorString(e) : "hipGetSymbolAddress returned null");
+        g_scratch_ptr[dev] = (double*)ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return DDN_OK;
+}
+}  // namespace
+
 // =============================================================================== C ABI
 extern "C" {
 
@@ -1172,6 +1203,11 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
     if (rc) {
         ddn_plan_destroy(p);
         return rc;
+    }
+    {
+        // set-up for ddn_reduce_static on this device, so that its first call has nothing left to resolve
+        double* unused = nullptr;
+        (void)static_scratch(&unused);
     }
     *out = p;
     return DDN_OK;
@@ -1357,6 +1393,23 @@ int ddn_reduce(int dtype, const void* x, const void* y, size_t n_per_image, int 
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     (void)hipFree(part);
+    return DDN_OK;
+}
+
+int ddn_reduce_static(int dtype, const void* x, const void* y, size_t n_per_image, int batch, double* out4, void* stream) {
+    if (!x || !out4 || batch < 1 || n_per_image == 0 || (dtype != DDN_F32 && dtype != DDN_F64)) return fail(DDN_E_ARG, "reduce_static: bad arguments");
+    if (batch > DDN_REDUCE_STATIC_MAX_BATCH) return fail(DDN_E_UNSUPPORTED, "reduce_static: more than DDN_REDUCE_STATIC_MAX_BATCH images (use ddn_reduce)");
+    double* part = nullptr;
+    int rc = static_scratch(&part);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // same launch shape as ddn_reduce, so the two give bit-identical sums; every slot that k_reduce_final
+    // reads is written by k_reduce_partial of this call: nothing in the array has to start at zero
+    const int chunks = (int)std::min<size_t>(kStaticChunks, std::max<size_t>(1, n_per_image / 4096));
+    if (dtype == DDN_F32) hipLaunchKernelGGL(k_reduce_partial<float>, dim3(chunks * batch), dim3(256), 0, st, (const float*)x, (const float*)y, n_per_image, chunks, part);
+    else hipLaunchKernelGGL(k_reduce_partial<double>, dim3(chunks * batch), dim3(256), 0, st, (const double*)x, (const double*)y, n_per_image, chunks, part);
+    hipLaunchKernelGGL(k_reduce_final, dim3(batch), dim3(64), 0, st, part, chunks, (double)n_per_image, out4);
+    HIPCHK(hipGetLastError());
     return DDN_OK;
 }
 

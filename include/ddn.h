@@ -125,6 +125,19 @@ int ddn_prox(int kind, int dtype, const void* x_dev, void* y_dev, size_t n, doub
  * out4_dev: [batch][4] doubles = {sum|d|, sqrt(sum d^2), mean d^2, 10 log10(1/mse)}. */
 int ddn_reduce(int dtype, const void* x_dev, const void* y_dev, size_t n_per_image, int batch, double* out4_dev, void* stream);
 
+/* Allocation-free variant of ddn_reduce.  It has no counterpart in the reference: it exists for callers
+ * that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  Same arguments, same kernels and launch shape, bit-identical out4_dev; the per-chunk
+ * partial sums live in a static device array of the library (512 KiB per GPU, held until the process
+ * ends) instead of a temporary buffer, so the call makes no hipMalloc / hipFree and, unlike ddn_reduce,
+ * does not synchronise: out4_dev is valid once `stream` has reached this point.
+ * Limit: batch <= DDN_REDUCE_STATIC_MAX_BATCH, else DDN_E_UNSUPPORTED.  All calls on one GPU share that
+ * GPU's array: calls that overlap on one GPU (different streams or threads) race; serialise them.
+ * The array's address is resolved once per device, at the first ddn_plan_create or the first call of
+ * this function on that device (do that first call outside graph capture). */
+#define DDN_REDUCE_STATIC_MAX_BATCH 128
+int ddn_reduce_static(int dtype, const void* x_dev, const void* y_dev, size_t n_per_image, int batch, double* out4_dev, void* stream);
+
 /* ssim (core/loss.py:39-110): 11 x 11 Gaussian window (sigma 1.5), zero padding, C1 = (0.01 max_val)^2,
  * C2 = (0.03 max_val)^2, mean of the SSIM map per plane.  x, y: [planes][H][W]; out_dev: [planes] doubles.
  * g11_host: the 11 normalised float32 window factors exactly as loss.py:75-81 computes them (the caller

@@ -33,14 +33,30 @@ WORDS_ITER = {"chambolle_pock": 23, "primal_dr_splitting": 18, "primal_dual_dr_s
 # the same count restricted to the fused row kernel (per launch): iterate reads + writes + 2 words of
 # half-spectra in + 2 out; Chambolle-Pock launches two row kernels per iteration (dual 10 + primal 7).
 WORDS_ROW = {"chambolle_pock": 17 / 2.0, "primal_dr_splitting": 13, "primal_dual_dr_splitting": 13, "admm_solver": 21}
+# the same for one launch of the column stage (both half-spectra in and out + the blur eigenvalues;
+# Chambolle-Pock: one half-spectrum in and out + the eigenvalues, two launches per iteration)
+WORDS_COL = {"chambolle_pock": 3, "primal_dr_splitting": 5, "primal_dual_dr_splitting": 5, "admm_solver": 5}
+ROW_KERNEL = {"chambolle_pock": "k_wave_cp", "primal_dr_splitting": "k_wave_row<pdr>", "primal_dual_dr_splitting": "k_wave_row<pddr>",
+              "admm_solver": "k_wave_row<admm>"}
+COL_KERNEL = {"chambolle_pock": "k_wave_col<multiplier>", "primal_dr_splitting": "k_wave_col<resolvent>",
+              "primal_dual_dr_splitting": "k_wave_col<resolvent>", "admm_solver": "k_wave_col<resolvent>"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-# HBM bytes per launch of each fused row kernel at 4096 x 4096, one image, from the rocprofv3 PMC passes
-# whose summary is committed under profiles/ (separate --pmc runs of this
-# same command): 2 x FETCH_SIZE (gfx950 reports half of the bytes of streaming reads) + WRITE_SIZE, KB -> bytes.
-# Full (consume + produce) launches only; Chambolle-Pock: mean of its dual-step and primal-step kernels.
-MEASURED_TRAFFIC_4096 = {"k_admm_row": 2 * 362.1e6 + 721.3e6, "k_pdr_row": 2 * 230.9e6 + 393.7e6,
-                         "k_pddr_row": 2 * 230.9e6 + 393.6e6,
-                         "k_cp_row": (2 * 197.9e6 + 262.2e6 + 2 * 164.5e6 + 196.8e6) / 2}
+
+
+def measured_traffic(lib_version, H, W, B):
+    """HBM bytes per full launch of each kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json, written by
+    tools/tools_pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction applied).  Only figures measured on
+    the library version that is running, at this problem size, are reported; otherwise null."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if rec.get("ddn_version") == lib_version and rec.get("size") == [H, W] and rec.get("batch") == B:
+            best = rec
+    return best
 
 
 def main():
@@ -186,32 +202,56 @@ def main():
             "iter_hbm_frac": WORDS_ITER[name] * 4.0 * px * K / sec / 1e9 / HBM_PEAK_GBS,
             "row_kernel_ms": row_ms, "col_kernel_ms": tm["col_ms"], "n_row": tm["n_row"], "n_col": tm["n_col"],
             "row_kernel_gbs": (WORDS_ROW[name] * 4.0 * px / (row_ms * 1e-3) / 1e9) if row_ms > 0 else None,
+            "col_kernel_gbs": (WORDS_COL[name] * 4.0 * px / (tm["col_ms"] * 1e-3) / 1e9) if tm["col_ms"] > 0 else None,
             "final_loss": [float(v) for v in ring[K - 1, 0, :4].cpu()],
         }
         ops.close()
         del st, ring
         torch.cuda.empty_cache()
 
-    DOMK = {"chambolle_pock": "k_cp_row", "primal_dr_splitting": "k_pdr_row", "primal_dual_dr_splitting": "k_pddr_row", "admm_solver": "k_admm_row"}
     nsol = len(solvers)
     px = float(B) * H * W
     value = world * px * K * nsol / total_time / 1e6
-    # dominant kernel = the fused row kernel with the largest share of the timed region
-    dom = max(per_solver, key=lambda s: per_solver[s]["row_kernel_ms"] * per_solver[s]["n_row"])
-    ach = per_solver[dom]["row_kernel_gbs"] or 0.0
+    # per-kernel table: mean launch duration (HIP events on the plan's stream), launches per step, algorithmic bytes
+    # per launch, achieved rate.  The dominant kernel is the one with the largest share of a step, row or column.
+    lib_version = int(lib.ddn_version())
+    pmc = measured_traffic(lib_version, H, W, B)
+    kernels = {}
+    for sname, ps in per_solver.items():
+        lpi = 2 if sname == "chambolle_pock" else 1
+        for kind, kname, words, ms in (("row", ROW_KERNEL[sname], WORDS_ROW[sname], ps["row_kernel_ms"]),
+                                       ("col", COL_KERNEL[sname], WORDS_COL[sname], ps["col_kernel_ms"])):
+            if not ms or ms <= 0:
+                continue
+            e = kernels.setdefault(kname, {"ms_per_step": 0.0, "launches_per_step": 0, "algorithmic_bytes": words * 4.0 * px, "_bytes": 0.0})
+            e["ms_per_step"] += ms * lpi
+            e["launches_per_step"] += lpi
+            e["_bytes"] += words * 4.0 * px * lpi
+    for kname, e in kernels.items():
+        e["ms"] = e["ms_per_step"] / e["launches_per_step"]
+        e["achieved_gbs"] = e.pop("_bytes") / (e["ms_per_step"] * 1e-3) / 1e9
+        e["frac"] = e["achieved_gbs"] / HBM_PEAK_GBS
+        e["traffic"] = (pmc or {}).get("kernels", {}).get(kname, {}).get("hbm_bytes_per_launch")
+    if kernels:
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        domk = kernels[dom]
+        roof = {"bound": "hbm", "achieved": domk["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": domk["frac"],
+                "traffic": domk["traffic"], "traffic_source": (pmc or {}).get("source"), "kernel": dom,
+                "algorithmic_bytes_per_launch": domk["algorithmic_bytes"], "kernel_ms": domk["ms"]}
+    else:
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": None}
+    roof["kernels"] = kernels
+    roof["whole_iteration_frac"] = {s_: per_solver[s_]["iter_hbm_frac"] for s_ in per_solver}
     out = {
         "metric": "Mpixel-iterations/sec per solver at 4096^2 + % HBM roofline",
         "value": value, "unit": "Mpixel-iterations/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": total_time / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{H}x{W} grayscale motion-blur (15 taps @45deg) deconvolution, fp32, all four solvers, reference default parameters",
-                   "images_per_gpu": B, "solvers": solvers, "step": "one iteration of each solver"},
+        "config": {"workload": f"{H}x{W} grayscale motion-blur (15 taps @45deg) deconvolution, fp32, all four solvers, reference default parameters"
+                               " (Chambolle-Pock's defaults t=0.4, s=0.7 are outside its stable range; its iterates are pinned against the reference for N <= 20 only)",
+                   "images_per_gpu": B, "solvers": solvers, "step": "one iteration of each solver", "ddn_version": lib_version},
         "per_solver": per_solver,
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                     "traffic": MEASURED_TRAFFIC_4096.get(DOMK[dom]) if (H == 4096 and W == 4096 and B == 1) else None,
-                     "kernel": DOMK[dom],
-                     "algorithmic_bytes_per_launch": WORDS_ROW[dom] * 4.0 * px,
-                     "whole_iteration_frac": {s: per_solver[s]["iter_hbm_frac"] for s in per_solver}},
+        "roofline": roof,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -220,25 +260,32 @@ def main():
         from oracle import ddn_oracle as O
         bc = b[0].cpu()
         kc = kern
-        n = args.cpu_iters
+        n = max(2, args.cpu_iters)
         cores = torch.get_num_threads()
-        tcpu = 0.0
-        its = 0
-        torch.manual_seed(7)
-        for name in solvers:
+
+        def cpu_run(name, n_it):
+            torch.manual_seed(7)
             t0 = time.perf_counter()
             if name == "chambolle_pock":
-                O.chambolle_pock(bc[None], kc, max_iter=n + 1, loss_function=O.psnr)
+                O.chambolle_pock(bc[None], kc, max_iter=n_it + 1, loss_function=O.psnr)
             elif name == "primal_dr_splitting":
-                O.primal_dr_splitting("l1", kc, bc, niters=n, loss_function=O.mse)
+                O.primal_dr_splitting("l1", kc, bc, niters=n_it, loss_function=O.mse)
             elif name == "primal_dual_dr_splitting":
-                O.primal_dual_dr_splitting(bc, kc, niters=n + 1, loss_function=O.l2_loss)
+                O.primal_dual_dr_splitting(bc, kc, niters=n_it + 1, loss_function=O.l2_loss)
             else:
-                O.admm_solver(bc, kernel=kc, niters=n + 1, loss_function=O.psnr)
-            tcpu += time.perf_counter() - t0
-            its += n
-        out["cpu_baseline"] = {"value": H * W * its / tcpu / 1e6, "unit": "Mpixel-iterations/s", "cores": cores, "kind": "port",
-                               "sample": f"{n} iteration(s) of each of the {len(solvers)} solvers at {H}x{W} (operator set-up and, for ADMM, the final solve included)"}
+                O.admm_solver(bc, kernel=kc, niters=n_it + 1, loss_function=O.psnr)
+            return time.perf_counter() - t0
+
+        # each solver once with 1 iteration and once with n: the difference is n - 1 iterations without the operator
+        # set-up (three conv2d + fft2 of the image size) and, for ADMM, without the final solve, which the GPU leg
+        # does not time either
+        t_one = sum(cpu_run(name, 1) for name in solvers)
+        t_n = sum(cpu_run(name, n) for name in solvers)
+        its = (n - 1) * len(solvers)
+        out["cpu_baseline"] = {"value": H * W * its / max(t_n - t_one, 1e-9) / 1e6, "unit": "Mpixel-iterations/s", "cores": cores, "kind": "port",
+                               "value_with_setup": H * W * n * len(solvers) / t_n / 1e6,
+                               "sample": f"{n - 1} iteration(s) of each of the {len(solvers)} solvers at {H}x{W}: time of an {n}-iteration run minus "
+                                         f"time of a 1-iteration run (operator set-up excluded, as in the GPU leg); value_with_setup: the {n}-iteration runs whole"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:

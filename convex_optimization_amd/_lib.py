@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libddn.so")
+# DDN_LIB_PATH: another build of the same library (A/B measurements of kernel variants)
+_LIB_PATH = os.environ.get("DDN_LIB_PATH") or os.path.join(_HERE, "libddn.so")
 
 F32, F64 = 0, 1
 C64, C128 = 0, 1

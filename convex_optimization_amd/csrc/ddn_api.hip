@@ -1171,7 +1171,7 @@ int static_scratch(double** out) {
 // =============================================================================== C ABI
 extern "C" {
 
-int ddn_version(void) { return 100; }
+int ddn_version(void) { return 200; }
 const char* ddn_last_error(void) { return ddn_err().c_str(); }
 
 int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* stream) {

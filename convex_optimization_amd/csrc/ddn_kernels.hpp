@@ -72,10 +72,16 @@ __device__ __forceinline__ T data_prox(int objective, T v, T lam, T div) {
 #endif
 }
 
+// DDN_NT_ITER (wave-per-row units): the iterate arrays are touched once per iteration, so their scalar
+// accesses carry the non-temporal hint and leave the caches to the spectra and the multipliers.
 template <typename T, int V>
 __device__ __forceinline__ void vload(const T* p, T (&r)[V]) {
     if constexpr (V == 1) {
+#ifdef DDN_NT_ITER
+        r[0] = __builtin_nontemporal_load(p);
+#else
         r[0] = p[0];
+#endif
     } else if constexpr (sizeof(T) == 4) {
         const float4 t = *reinterpret_cast<const float4*>(p);
         r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
@@ -88,7 +94,11 @@ __device__ __forceinline__ void vload(const T* p, T (&r)[V]) {
 template <typename T, int V>
 __device__ __forceinline__ void vstore(T* p, const T (&r)[V]) {
     if constexpr (V == 1) {
+#ifdef DDN_NT_ITER
+        __builtin_nontemporal_store(r[0], p);
+#else
         p[0] = r[0];
+#endif
     } else if constexpr (sizeof(T) == 4) {
         *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
     } else {

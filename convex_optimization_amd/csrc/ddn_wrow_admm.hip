@@ -3,6 +3,9 @@
 // (rows 4g .. 4g+3) with 4-column tiles.  Load-pipeline depth 2: measured best (the kernel is not
 // latency-bound on the iterate loads; deeper pipelines only cost registers).
 #define DDN_WAVE_FAST 1
+#ifndef DDN_NO_NT_ITER
+#define DDN_NT_ITER 1  // non-temporal iterate accesses (ddn_wrow.hpp, ldi / sti)
+#endif
 #include "ddn_launch.hpp"
 #include "ddn_wrow.hpp"
 

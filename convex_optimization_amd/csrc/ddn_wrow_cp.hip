@@ -1,6 +1,9 @@
 // Wave-per-row Chambolle-Pock kernels (W = 4096, float); one wave (one row pair) per workgroup with
 // 16-column spectral tiles, four with 4-column tiles.
 #define DDN_WAVE_FAST 1
+#ifndef DDN_NO_NT_ITER
+#define DDN_NT_ITER 1  // non-temporal iterate accesses (ddn_wrow.hpp, ldi / sti)
+#endif
 #include "ddn_launch.hpp"
 #include "ddn_wrow.hpp"
 

@@ -240,8 +240,8 @@ template <int PD, int SL, int R>
 __device__ __forceinline__ void cp_dualN(cx<float> (&d)[64], const CpArgs<float>& a, int lane) {
     struct Q { float z, y0, y1, y2, b; } q[PD];
     const unsigned lo = (unsigned)lane;
-#define DDN_CP_LD(r, e) { (e).z = opaque_ptr(a.z + 64 * (r))[lo]; (e).y0 = opaque_ptr(a.y0 + 64 * (r))[lo]; (e).y1 = opaque_ptr(a.y1 + 64 * (r))[lo]; (e).y2 = opaque_ptr(a.y2 + 64 * (r))[lo]; (e).b = opaque_ptr(a.b + 64 * (r))[lo]; }
-    float zl = opaque_ptr(a.z + 64 * (R - 1))[lo];  // last register of the row: z[-1] of lane 0
+#define DDN_CP_LD(r, e) { (e).z = ldi(opaque_ptr(a.z + 64 * (r)), lo); (e).y0 = ldi(opaque_ptr(a.y0 + 64 * (r)), lo); (e).y1 = ldi(opaque_ptr(a.y1 + 64 * (r)), lo); (e).y2 = ldi(opaque_ptr(a.y2 + 64 * (r)), lo); (e).b = ldi(opaque_ptr(a.b + 64 * (r)), lo); }
+    float zl = ldi(opaque_ptr(a.z + 64 * (R - 1)), lo);  // last register of the row: z[-1] of lane 0
 #pragma unroll
     for (int g = 0; g < PD; ++g) DDN_CP_LD(g, q[g])
     float rot_prev = 0.f;
@@ -251,7 +251,7 @@ __device__ __forceinline__ void cp_dualN(cx<float> (&d)[64], const CpArgs<float>
         sched_fence();
         if (j == 0) {
             rot_prev = from_prev_lane(zl);
-            if (r + R < 64) zl = opaque_ptr(a.z + 64 * (r + 2 * R - 1))[lo];  // for the next row, a row ahead
+            if (r + R < 64) zl = ldi(opaque_ptr(a.z + 64 * (r + 2 * R - 1)), lo);  // for the next row, a row ahead
         }
         const Q e = q[r % PD];
         if (r + PD < 64) DDN_CP_LD(r + PD, q[r % PD])
@@ -266,9 +266,9 @@ __device__ __forceinline__ void cp_dualN(cx<float> (&d)[64], const CpArgs<float>
         const float y0n = g0 - a.s * e.b - a.s * pr0;
         float i1, i2;
         iso(udiv(g1, a.s), udiv(g2, a.s), a.isg, i1, i2);                         // cp:75
-        opaque_ptr(a.y0 + 64 * r)[lo] = y0n;
-        opaque_ptr(a.y1 + 64 * r)[lo] = g1 - a.s * i1;
-        opaque_ptr(a.y2 + 64 * r)[lo] = g2 - a.s * i2;
+        sti(opaque_ptr(a.y0 + 64 * r), lo, y0n);
+        sti(opaque_ptr(a.y1 + 64 * r), lo, g1 - a.s * i1);
+        sti(opaque_ptr(a.y2 + 64 * r), lo, g2 - a.s * i2);
         slot<SL>(d[r]) = y0n;
         asm volatile("" : "+v"(slot<SL>(d[r])));
     }
@@ -281,7 +281,7 @@ template <int PD, int SL, int R>
 __device__ __forceinline__ void cp_primalN(cx<float> (&d)[64], const CpArgs<float>& a, int lane, double* partials) {
     struct Q { float x, b, y1, y2; } q[PD];
     const unsigned lo = (unsigned)lane;
-#define DDN_CP_LD(r, e) { (e).x = opaque_ptr(a.x + 64 * (r))[lo]; (e).b = opaque_ptr(a.b + 64 * (r))[lo]; (e).y1 = opaque_ptr(a.y1 + 64 * (r))[lo]; (e).y2 = opaque_ptr(a.y2 + 64 * (r))[lo]; }
+#define DDN_CP_LD(r, e) { (e).x = ldi(opaque_ptr(a.x + 64 * (r)), lo); (e).b = ldi(opaque_ptr(a.b + 64 * (r)), lo); (e).y1 = ldi(opaque_ptr(a.y1 + 64 * (r)), lo); (e).y2 = ldi(opaque_ptr(a.y2 + 64 * (r)), lo); }
 #pragma unroll
     for (int g = 0; g < PD; ++g) DDN_CP_LD(g, q[g])
     double acc[4] = {0, 0, 0, 0};
@@ -293,8 +293,8 @@ __device__ __forceinline__ void cp_primalN(cx<float> (&d)[64], const CpArgs<floa
         const float zn = 2.f * xn - x_prev;                                       /* cp:87 */  \
         const float dd = xn - b_prev;                                             /* cp:96 */  \
         acc[0] += (double)t_abs(dd); acc[1] += (double)dd * (double)dd;                         \
-        opaque_ptr(a.x + 64 * (r))[lo] = xn;                                                    \
-        opaque_ptr(a.z + 64 * (r))[lo] = zn;                                                    \
+        sti(opaque_ptr(a.x + 64 * (r)), lo, xn);                                                    \
+        sti(opaque_ptr(a.z + 64 * (r)), lo, zn);                                                    \
         slot<SL>(d[r]) = zn;                                                                    \
         asm volatile("" : "+v"(slot<SL>(d[r]))); }
 #pragma unroll

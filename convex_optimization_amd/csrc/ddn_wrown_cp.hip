@@ -1,6 +1,9 @@
 // Wave-per-row-group Chambolle-Pock kernels for W = 512, 1024, 2048 (float): 2 * 64 / (W / 64) rows per
 // wavefront (ddn_wrown.hpp).
 #define DDN_WAVE_FAST 1
+#ifndef DDN_NO_NT_ITER
+#define DDN_NT_ITER 1  // non-temporal iterate accesses (ddn_wrow.hpp, ldi / sti)
+#endif
 #include "ddn_launch.hpp"
 #include "ddn_wrown.hpp"
 

@@ -160,6 +160,11 @@ struct ddn_plan {
     void* eKc = nullptr;     // column-major natural-order copies of eK and G for the wave-per-column stage
     void* Gcm = nullptr;
     bool eKc_ok = false, Gcm_ok = false;
+    void* nyq_taps = nullptr;  // blur taps transformed along the rows at column W/2 (real, kh entries): see RowCommon::nyq_taps
+    int nyq_kh = 0, nyq_ph = 0;
+    bool nyq_fir_on = false;   // a Chambolle-Pock loop runs with column W/2 handled by the row kernels
+    void* ctab = nullptr;    // [Wh][2][32] complex: the blur taps transformed along the rows, for the H = 4096 column stage (wcol::taps_mult)
+    bool ctab_ok = false;
     double g_cK = 0, g_cD = 0;  // coefficients of the closed-form resolvent multiplier (when Gcm_ok)
     void* twH = nullptr;   // table of length H (outer twiddles and single-pass column transform)
     void* twA = nullptr;
@@ -246,8 +251,6 @@ bool choose_col(ddn_plan* p) {
         while ((1 << lim) < p->tune_cols) ++lim;
     }
     p->cs = std::min(c2, lim);
-    // experimental: 4-column tiles for the wave-per-column stage (every 128-byte line belongs to one column workgroup)
-    if (sizeof(T) == 4 && p->H == 4096 && p->tune_cols == 0 && getenv("DDN_TILE4")) p->cs = 2;
     p->ntile = (p->Wh + (1 << p->cs) - 1) >> p->cs;
     // tiles a power of two apart would put the rows that resident workgroups stream in lockstep at the
     // same offset modulo the DRAM channel interleave: pad the tile pitch for large power-of-two heights
@@ -408,7 +411,7 @@ inline int col_threads_for(const ddn_plan* p, int n, int cs, int narr) {
 inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
 
 inline bool wcol_ready(const ddn_plan* p) {
-    return p->eKc_ok && p->wtw && p->H == 4096 && (p->cs == 4 || p->cs == 2) && !p->injected && !p->slab_cols && !getenv("DDN_NO_WAVE_COLS");
+    return p->eKc_ok && p->wtw && p->H == 4096 && p->cs == 4 && !p->injected && !p->slab_cols && !getenv("DDN_NO_WAVE_COLS");
 }
 // H = 512 / 1024 / 2048: several adjacent columns per wavefront (ddn_wcoln.hpp)
 inline bool wcoln_ready(const ddn_plan* p) {
@@ -442,13 +445,17 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
             w.eKc = (const cx<float>*)p->eKc; w.wtw = (const cx<float>*)p->wtw;
             w.ed2 = (const float*)p->ed2; w.cK = (float)p->g_cK; w.cD = (float)p->g_cD; w.gscale = (float)(1.0 / ((double)p->H * (double)p->W));
             w.lay = layout_of(p); w.Wh = p->Wh; w.batch = nplanes;
-            // experimental: columns 0 and W/2 share one wave (exact, but its workgroup is slower than a plain one)
-            w.nyq_packed = (p->W % 2 == 0 && getenv("DDN_NYQ_PACK")) ? 1 : 0;
+            const bool fir = MODE == COL_MUL && p->nyq_fir_on;   // column W/2 is the row kernels' business
+            if (fir) w.Wh = p->Wh - 1;
+            w.ctab = (wave1 && p->ctab_ok) ? (const cx<float>*)p->ctab : nullptr;
             w.conj_mult = conj_mult; w.scale = (float)scale; w.lf = lf;
-            w.nyqd = p->nyqd_on ? (float*)p->nyqd : nullptr;
+            w.nyqd = (p->nyqd_on && !fir) ? (float*)p->nyqd : nullptr;
             w.ilv = (p->ilv_on && MODE == COL_RES2) ? 1 : 0;
             w.dbg = p->dbg ? p->dbg + 4096 * 16 : nullptr;  // second half of the stamp buffer
-            w.dbg_mode = getenv("DDN_DEBUG_CMODE") ? atoi(getenv("DDN_DEBUG_CMODE")) : 0;
+            if (MODE == COL_MUL && getenv("DDN_COL_STAGGER")) {
+                w.stagger_clks = atoi(getenv("DDN_COL_STAGGER"));
+                w.stagger_first = 2 * p->num_cu + 32;
+            }
             TimerScope ts(p, false);
             if (waven) {
                 w.wtw = (const cx<float>*)p->wtwH;
@@ -542,12 +549,10 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
         rc.grid = std::max(1, std::min(items, p->num_cu * 8));
         return true;
     }
-    if (sizeof(T) == 4 && p->wtw && W == 4096 && !p->injected && wave_pays && !getenv("DDN_NO_WAVE_ROWS")) {
+    if (sizeof(T) == 4 && p->wtw && W == 4096 && p->cs == 4 && !p->injected && wave_pays && !getenv("DDN_NO_WAVE_ROWS")) {
         // one wavefront per row, eight per CU (256 registers each), the row held in registers
-        // (four rows per workgroup with 4-column spectral tiles, see ddn_wrow.hpp)
-        const int wpw = p->cs == 2 ? 4 : 1;
-        rc.V = 0; rc.threads = 64 * wpw; rc.lds = 0;
-        rc.grid = std::max(1, std::min((work_items + wpw - 1) / wpw, p->num_cu * 8 / wpw));
+        rc.V = 0; rc.threads = 64; rc.lds = 0;
+        rc.grid = std::max(1, std::min(work_items, p->num_cu * 8));
         return true;
     }
     if (aligned && W % 4 == 0 && W <= 4096) {
@@ -766,6 +771,53 @@ int set_resolvent_impl(ddn_plan* p, double cK, double cD, const void* M_dev, int
     return DDN_OK;
 }
 
+// Table for wcol::taps_mult (H = 4096, blur kernels of at most 31 rows): per spectral column k2 and register parity,
+// 32 complex values y-coefficients c_n(k2) = sum_v tap[ph - n][v] exp(-2 pi i k2 (pw - v) / W) at slot j = n mod 32
+// (n = ph - u in [-15, 15]), the odd-parity copy times w64^j (-1)^[n < 0].  Taps rounded to float first (eig:49).
+int make_ctab(ddn_plan* p, const double* taps, int kh, int kw) {
+    const int Wh = p->Wh, W = p->W, ph = kh / 2, pw = kw / 2;
+    const long double tp = -2.0L * 3.14159265358979323846264338327950288L;
+    std::vector<cx<float>> tab((size_t)Wh * 64);
+    for (auto& e : tab) e = {0.f, 0.f};
+    std::vector<long double> cw(kw), sw(kw);
+    for (int k2 = 0; k2 < Wh; ++k2) {
+        for (int v = 0; v < kw; ++v) {
+            const long long m = (((long long)k2 * (pw - v)) % W + W) % W;
+            cw[v] = cosl(tp * (long double)m / (long double)W);
+            sw[v] = sinl(tp * (long double)m / (long double)W);
+        }
+        for (int u = 0; u < kh; ++u) {
+            const int n = ph - u, j = ((n % 32) + 32) % 32;
+            long double re = 0, im = 0;
+            for (int v = 0; v < kw; ++v) {
+                const long double t = (long double)(float)taps[u * kw + v];
+                re += t * cw[v];
+                im += t * sw[v];
+            }
+            tab[(size_t)k2 * 64 + j] = {(float)re, (float)im};
+            const long double a = tp * (long double)j / 64.0L, sg = n < 0 ? -1.0L : 1.0L;
+            const long double c = cosl(a) * sg, s_ = sinl(a) * sg;
+            tab[(size_t)k2 * 64 + 32 + j] = {(float)(re * c - im * s_), (float)(re * s_ + im * c)};
+        }
+    }
+    // column W/2: exp(-2 pi i (W/2) (pw - v) / W) = (-1)^(pw - v), so its taps along the rows are real
+    std::vector<float> nt(32, 0.f);
+    for (int u = 0; u < kh; ++u) {
+        long double a = 0;
+        for (int v = 0; v < kw; ++v) a += (long double)(float)taps[u * kw + v] * (((pw - v) & 1) ? -1.0L : 1.0L);
+        nt[u] = (float)a;
+    }
+    if (!p->nyq_taps) HIPCHK(hipMalloc(&p->nyq_taps, 32 * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(p->nyq_taps, nt.data(), 32 * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    p->nyq_kh = kh;
+    p->nyq_ph = ph;
+    if (!p->ctab) HIPCHK(hipMalloc(&p->ctab, tab.size() * sizeof(cx<float>)));
+    HIPCHK(hipMemcpyAsync(p->ctab, tab.data(), tab.size() * sizeof(cx<float>), hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    p->ctab_ok = true;
+    return DDN_OK;
+}
+
 // While a solver loop runs entirely on the wave kernels, spectral column W/2 lives in a dense side
 // array instead of the last tile (where it would use 8 bytes of every 128-byte line).
 struct NyqDense {
@@ -776,7 +828,7 @@ struct NyqDense {
         p->ilv_on = false;
         if (!wave_rows) return;
         // both stages on the wave kernels: interleave the two half-spectra (not with 4-column tiles)
-        p->ilv_on = res2 && (wcol_ready(p) || wcoln_ready(p)) && p->cs > 2 && p->Gcm_ok && !getenv("DDN_NYQ_PACK") && !getenv("DDN_NO_ILV");
+        p->ilv_on = res2 && (wcol_ready(p) || wcoln_ready(p)) && p->cs > 2 && p->Gcm_ok && !getenv("DDN_NO_ILV");
         if (p->W != 4096 || !wcol_ready(p) || p->W % 2 || (p->Wh & 3) != 1 || getenv("DDN_NO_NYQ_DENSE")) return;
         if (!p->nyqd && hipMalloc(&p->nyqd, sizeof(float) * 2 * (size_t)p->batch * p->H) != hipSuccess) { p->nyqd = nullptr; return; }
         p->nyqd_on = true;
@@ -901,6 +953,21 @@ int cp_run_impl(ddn_plan* p, void* x, void* z, void* y, const void* b, double t,
     const bool al = aligned16(x) && aligned16(z) && aligned16(y) && aligned16(b) && ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, p->batch * ((p->H + 1) / 2), cfg, true)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
     NyqDense nyq_guard(p, cfg.V == 0);
+    // column W/2 as a short correlation along the rows inside the row kernels (RowCommon::nyq_taps): the column stage
+    // then has exactly 512 quarter tiles for the chip's 512 workgroup slots instead of 513
+    struct FirGuard {
+        ddn_plan* p;
+        ~FirGuard() { p->nyq_fir_on = false; }
+    } fir_guard{p};
+    p->nyq_fir_on = p->nyqd_on && p->ctab_ok && p->nyq_taps && p->nyq_kh <= 32 && sizeof(T) == 4 && !getenv("DDN_NO_NYQ_FIR");
+    int flip = 0;
+    auto with_fir = [&](RowCommon<T>& rc_, int dir) {
+        if (!p->nyq_fir_on) return;
+        rc_.nyq_taps = (const T*)p->nyq_taps;
+        rc_.nyq_kh = p->nyq_kh; rc_.nyq_ph = p->nyq_ph; rc_.nyq_dir = dir; rc_.nyq_flip = flip;
+        rc_.nyq_scale = (T)(1.0 / (double)p->W);
+        flip ^= 1;
+    };
     CpArgs<T> a;
     RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
@@ -913,6 +980,7 @@ int cp_run_impl(ddn_plan* p, void* x, void* z, void* y, const void* b, double t,
         a.step = 1;
         rc0 = row_common<T>(p, cfg.V, false, true);
         rc0.stop = nullptr;
+        with_fir(rc0, 1);
         if ((rc = launch_cp_row<T>(p, cfg, rc0, a))) return rc;
         for (int c = 1; c <= n_iters; ++c) {
             LossFin lf = make_lf(p, ring, c - 1, 0, 0.0, 1, false);
@@ -920,11 +988,13 @@ int cp_run_impl(ddn_plan* p, void* x, void* z, void* y, const void* b, double t,
             a.step = 0;
             rc0 = row_common<T>(p, cfg.V, true, true);
             rc0.stop = nullptr;
+            with_fir(rc0, 1);     // consumes K z
             if ((rc = launch_cp_row<T>(p, cfg, rc0, a))) return rc;
             if ((rc = col_stage<T, COL_MUL>(p, p->batch, (const cx<T>*)p->eK, nullptr, nullptr, 1, scale, no_loss()))) return rc;
             a.step = 1;
             rc0 = row_common<T>(p, cfg.V, true, c < n_iters);
             rc0.stop = nullptr;
+            with_fir(rc0, -1);    // consumes K^T y0
             if ((rc = launch_cp_row<T>(p, cfg, rc0, a))) return rc;
         }
         if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, 0, 0.0, 1, false)))) return rc;
@@ -1070,6 +1140,7 @@ int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles, int conj_mu
             w.S0 = (cx<float>*)spec;
             w.S1 = (cx<float>*)spec + s1_off;
             w.eKc = (const cx<float>*)p->eKc + (size_t)col_lo * wcol::kColPitch;
+            w.ctab = (wave1 && p->ctab_ok) ? (const cx<float>*)p->ctab + (size_t)col_lo * 64 : nullptr;
             w.wtw = (const cx<float>*)(wave1 ? p->wtw : p->wtwH);
             w.ed2 = (const float*)p->ed2 + col_lo;
             w.cK = (float)p->g_cK; w.cD = (float)p->g_cD; w.gscale = (float)(1.0 / ((double)p->H * (double)p->W));
@@ -1215,7 +1286,7 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
 
 int ddn_plan_destroy(ddn_plan* p) {
     if (!p) return DDN_OK;
-    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->nyqd, p->eKc, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
+    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->nyqd, p->nyq_taps, p->eKc, p->ctab, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : p->ev_pool) {
@@ -1259,7 +1330,11 @@ int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
     p->have_K = true;
     p->injected = false;
     p->eKc_ok = p->Gcm_ok = false;
-    if (p->dtype == DDN_F32 && ((p->wtw && p->H == 4096 && (p->cs == 4 || p->cs == 2)) || (p->wtwH && (1 << p->cs) >= 4096 / p->H && p->cs <= 4))) {
+    p->ctab_ok = false;
+    if (p->dtype == DDN_F32 && p->wtw && p->H == 4096 && p->cs == 4 && kh <= 31 && !getenv("DDN_NO_TAPS")) {
+        if ((rc = make_ctab(p, taps, kh, kw))) return rc;
+    }
+    if (p->dtype == DDN_F32 && ((p->wtw && p->H == 4096 && p->cs == 4) || (p->wtwH && (1 << p->cs) >= 4096 / p->H && p->cs <= 4))) {
         if ((rc = make_colmajor<float>(p, (const cx<float>*)p->eK, nullptr, &p->eKc, nullptr))) return rc;
         p->eKc_ok = true;
     }
@@ -1273,7 +1348,7 @@ int ddn_plan_set_eig(ddn_plan* p, const void* eigK, const void* eigD, int cdtype
     else rc = import_full<double>(p, eigK, cdtype, 0, 0, 1.0, (cx<double>*)p->eK, nullptr);
     if (rc) return rc;
     p->have_K = true;
-    p->eKc_ok = p->Gcm_ok = false;
+    p->eKc_ok = p->Gcm_ok = p->ctab_ok = false;
     // row-spectral D table: Hermitian-symmetrised first row of eigD, or the analytic 1 - w^k
     const int W = p->W, Wh = p->Wh;
     std::vector<double> row(2 * (size_t)W);

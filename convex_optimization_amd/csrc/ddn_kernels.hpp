@@ -91,6 +91,16 @@ __device__ __forceinline__ void vload(const T* p, T (&r)[V]) {
         r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
     }
 }
+// b, the blurred image: read-only and small enough to stay in the last-level cache beside the half-spectra, so its
+// loads keep the default policy even where the iterate arrays are streamed
+template <typename T, int V>
+__device__ __forceinline__ void vload_keep(const T* p, T (&r)[V]) {
+    if constexpr (V == 1) {
+        r[0] = p[0];
+    } else {
+        vload<T, V>(p, r);
+    }
+}
 template <typename T, int V>
 __device__ __forceinline__ void vstore(T* p, const T (&r)[V]) {
     if constexpr (V == 1) {
@@ -455,6 +465,14 @@ struct RowCommon {
     int ilv;             // S0 holds the (S0, S1) pairs interleaved element by element (wave kernels only); S1 unused
     long long* dbg;      // diagnostic builds only: per-workgroup phase stamps (null = off)
     int dbg_mode;        // diagnostic: bit0 skip the transforms, bit1 skip pack/unpack, bit2 skip iterate stores
+    // Chambolle-Pock on the wave kernels: spectral column W/2 never enters the column stage.  Its multiplier is the
+    // transform of nyq_kh real taps, so K (or K^T) acts on it as a short circular correlation along the rows, which the
+    // consuming row launch evaluates itself from the values the previous launch left in the dense array:
+    //   out[row] = nyq_scale * sum_u nyq_taps[u] * in[(row + nyq_dir * (u - nyq_ph)) mod H].
+    // The dense array's two halves (per image) alternate as input and output: nyq_flip = 1 reads the second, writes the first.
+    const T* nyq_taps;   // null = off (column W/2 goes through the column stage)
+    int nyq_kh, nyq_ph, nyq_dir, nyq_flip;
+    T nyq_scale;
 };
 
 // LDS carve-up shared by all row kernels: data | twiddles | reduction scratch | edge values
@@ -507,7 +525,7 @@ struct PdrP {
         vload<T, V>(a.z20 + o, q.z20);
         vload<T, V>(a.z21 + o, q.z21);
         vload<T, V>(a.z22 + o, q.z22);
-        vload<T, V>(a.b + o, q.b);
+        vload_keep<T, V>(a.b + o, q.b);
     }
     template <int V>
     static __device__ __forceinline__ void step(const Args& a, bool consume, bool produce, size_t o, const T (&u)[V], const T (&k)[V], const T (&du)[V],
@@ -578,7 +596,7 @@ struct PddrP {
         vload<T, V>(a.q0 + o, q.q0);
         vload<T, V>(a.q1 + o, q.q1);
         vload<T, V>(a.q2 + o, q.q2);
-        vload<T, V>(a.b + o, q.b);
+        vload_keep<T, V>(a.b + o, q.b);
     }
     template <int V>
     static __device__ __forceinline__ void step(const Args& a, bool consume, bool produce, size_t o, const T (&w)[V], const T (&kw)[V], const T (&dw)[V],
@@ -639,7 +657,7 @@ struct AdmmP {
     };
     template <int V>
     static __device__ __forceinline__ void load(const Args& a, size_t o, St<V>& q) {
-        vload<T, V>(a.b + o, q.b);
+        vload_keep<T, V>(a.b + o, q.b);
         if (a.sol_only) return;
         vload<T, V>(a.u + o, q.u);
         vload<T, V>(a.w + o, q.w);

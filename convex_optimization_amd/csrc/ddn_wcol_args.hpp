@@ -14,22 +14,23 @@ struct Args {
     cx<float>* S0;
     cx<float>* S1;
     const cx<float>* eKc;  // [Wh][kColPitch], natural frequency order along the column
+    const cx<float>* ctab; // [Wh][2][32]: the blur taps transformed along the rows (wcol::taps_mult), or null = read eKc
     const float* ed2;      // |eD|^2 per column (Wh entries): the resolvent multiplier is recomputed per frequency,
     float cK, cD, gscale;  //   g = gscale / (1 + cK |e|^2 + cD ed2[k2])  (mm:67-72), which saves reading a third array
     const cx<float>* wtw;  // per-lane twiddles of the 4096-point transform
     SpecLayout lay;
     int Wh, batch;
     float* nyqd;           // dense home of column W/2 (real parts, [batch][2 arrays][H]) or null = inside the last tile
-    int nyq_packed;        // W even: column W/2 (real-valued, like column 0) rides in the imaginary part of column 0
     int conj_mult;
     float scale;
     LossFin lf;
     long long* dbg;        // diagnostic: per-workgroup phase stamps (16 per workgroup) or null
+    int stagger_clks;      // > 0: first-round workgroups in an odd wave slot start this many clocks late (see k_wave_col)
+    int stagger_first;     //   block indices below this count as first round
     int ilv;               // resolvent mode: S0 holds the (S0, S1) pairs interleaved element by element
     int Hfft;              // transform length when lay.H is only a pitch (0: lay.H is both)
     int rb_sh6;            // rows stored in blocks of 64 << rb_sh6 rows (one block per source rank of a row-slab
     long long rb_extra;    //   decomposition): block i starts i * rb_extra elements past its place in a plain tile; 0 = plain
-    int dbg_mode;          // diagnostic ablations (results wrong by construction): bit0 no multiplier loads, bit1 no exchange, bit2 every slab reads slab 0
 };
 
 // Column-major natural-order copies of the multipliers: outc[k2][k1] = tiled[pos(k1)][k2].

@@ -327,8 +327,8 @@ template <int PD, int SL>
 __device__ __forceinline__ void cp_dual(cx<float> (&d)[64], const CpArgs<float>& a, int lane) {
     struct Q { float z, y0, y1, y2, b; } q[PD];
     const unsigned lo = (unsigned)lane;
-#define DDN_CP_LD(r, e) { (e).z = ldi(opaque_ptr(a.z + 64 * (r)), lo); (e).y0 = ldi(opaque_ptr(a.y0 + 64 * (r)), lo); (e).y1 = ldi(opaque_ptr(a.y1 + 64 * (r)), lo); (e).y2 = ldi(opaque_ptr(a.y2 + 64 * (r)), lo); (e).b = ldi(opaque_ptr(a.b + 64 * (r)), lo); }
-    float zl = ldi(opaque_ptr(a.z + 64 * 63), lo);
+#define DDN_CP_LD(r, e) { (e).z = opaque_ptr(a.z + 64 * (r))[lo]; (e).y0 = ldi(opaque_ptr(a.y0 + 64 * (r)), lo); (e).y1 = ldi(opaque_ptr(a.y1 + 64 * (r)), lo); (e).y2 = ldi(opaque_ptr(a.y2 + 64 * (r)), lo); (e).b = opaque_ptr(a.b + 64 * (r))[lo]; }
+    float zl = opaque_ptr(a.z + 64 * 63)[lo];
 #pragma unroll
     for (int g = 0; g < PD; ++g) DDN_CP_LD(g, q[g])
     float rot_prev = from_prev_lane(zl);  // z[-1] of lane 0 = z[4095]
@@ -364,7 +364,7 @@ __device__ __forceinline__ void cp_primal(cx<float> (&d)[64], const CpArgs<float
     double acc[4] = {0, 0, 0, 0};
     struct Q { float x, b, y1, y2; } q[PD];
     const unsigned lo = (unsigned)lane;
-#define DDN_CP_LD(r, e) { (e).x = ldi(opaque_ptr(a.x + 64 * (r)), lo); (e).b = ldi(opaque_ptr(a.b + 64 * (r)), lo); (e).y1 = ldi(opaque_ptr(a.y1 + 64 * (r)), lo); (e).y2 = ldi(opaque_ptr(a.y2 + 64 * (r)), lo); }
+#define DDN_CP_LD(r, e) { (e).x = ldi(opaque_ptr(a.x + 64 * (r)), lo); (e).b = opaque_ptr(a.b + 64 * (r))[lo]; (e).y1 = ldi(opaque_ptr(a.y1 + 64 * (r)), lo); (e).y2 = ldi(opaque_ptr(a.y2 + 64 * (r)), lo); }
 #pragma unroll
     for (int g = 0; g < PD; ++g) DDN_CP_LD(g, q[g])
     // D^T(y1 + y2)[j] = s[j] - s[j+1]: register r is finished when s of register r+1 is known
@@ -376,7 +376,7 @@ __device__ __forceinline__ void cp_primal(cx<float> (&d)[64], const CpArgs<float
         const float dd = xn - b_prev;                                             /* cp:96 */  \
         acc[0] += (double)t_abs(dd); acc[1] += (double)dd * (double)dd;                         \
         sti(opaque_ptr(a.x + 64 * (r)), lo, xn);                                                    \
-        sti(opaque_ptr(a.z + 64 * (r)), lo, zn);                                                    \
+        opaque_ptr(a.z + 64 * (r))[lo] = zn;                                                    \
         slot<SL>(d[r]) = zn;                                                                    \
         asm volatile("" : "+v"(slot<SL>(d[r]))); }
 #pragma unroll
@@ -437,12 +437,30 @@ __global__ void __launch_bounds__(64 * WPW, 2) k_wave_cp(RowCommon<float> c, CpA
         advance(a1, opaque((row0 + 1) * 4096));
         cx<float>* const rw0 = c.S0 + opaque(sb0);
         cx<float>* const rw1 = c.S0 + opaque(sb1);
-        float* const nqa = c.nyqd ? c.nyqd + ((size_t)plane * 2 * H + r0) : nullptr;
+        // column W/2: the dense array [image][2][H]; with nyq_taps its halves alternate as input and output
+        const bool fir = c.nyq_taps != nullptr;
+        float* const nqa = c.nyqd ? c.nyqd + ((size_t)plane * 2 * H + ((fir && !c.nyq_flip) ? H : 0) + r0) : nullptr;
         float* const nqb = c.nyqd ? nqa + 1 : nullptr;
         cx<float> d[64];
         if (CONS) {
-            if (two) pack<true>(d, rw0, rw1, sa, lane, nqa, nqb);
-            else pack<false>(d, rw0, nullptr, sa, lane, nqa, nullptr);
+            float un = 0.f, vn = 0.f;
+            if (fir) {
+                // K or K^T on column W/2 as a correlation along the rows (uniform loads, a few dozen multiply-adds)
+                const float* const in = c.nyqd + ((size_t)plane * 2 * H + (c.nyq_flip ? H : 0));
+                for (int u = 0; u < c.nyq_kh; ++u) {
+                    const int s = c.nyq_dir * (u - c.nyq_ph);
+                    const int ra = (r0 + s + H) % H, rb = (r0 + 1 + s + H) % H;
+                    const float t = c.nyq_taps[u];
+                    un += t * in[ra];
+                    vn += t * in[rb];
+                }
+                un *= c.nyq_scale;
+                vn *= c.nyq_scale;
+            }
+            const float* const pa = fir ? &un : nqa;
+            const float* const pb = fir ? &vn : nqb;
+            if (two) pack<true>(d, rw0, rw1, sa, lane, pa, pb);
+            else pack<false>(d, rw0, nullptr, sa, lane, pa, nullptr);
             wfft::fft4096<true>(d, c.wtw, tile, lane);
             pin(d);
         } else {

@@ -17,5 +17,5 @@ static int go(hipStream_t st, int grid, const RowCommon<float>& c, const CpArgs<
 }
 
 int wrow_cp_launch(hipStream_t st, int grid, const RowCommon<float>& c, const CpArgs<float>& a) {
-    return c.lay.cs == 2 ? go<4>(st, grid, c, a) : go<1>(st, grid, c, a);
+    return go<1>(st, grid, c, a);
 }

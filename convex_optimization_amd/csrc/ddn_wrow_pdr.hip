@@ -28,5 +28,5 @@ static int go_ilv(hipStream_t st, int grid, const RowCommon<float>& c, const Pdr
 template <>
 int wrow_launch<PdrP<float>>(hipStream_t st, int grid, const RowCommon<float>& c, const PdrP<float>::Args& a) {
     if (c.ilv) return c.lay.cs == 4 ? go_ilv(st, grid, c, a) : DDN_E_UNSUPPORTED;
-    return c.lay.cs == 2 ? go<4>(st, grid, c, a) : go<1>(st, grid, c, a);
+    return go<1>(st, grid, c, a);
 }

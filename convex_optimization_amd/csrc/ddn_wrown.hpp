@@ -240,7 +240,7 @@ template <int PD, int SL, int R>
 __device__ __forceinline__ void cp_dualN(cx<float> (&d)[64], const CpArgs<float>& a, int lane) {
     struct Q { float z, y0, y1, y2, b; } q[PD];
     const unsigned lo = (unsigned)lane;
-#define DDN_CP_LD(r, e) { (e).z = ldi(opaque_ptr(a.z + 64 * (r)), lo); (e).y0 = ldi(opaque_ptr(a.y0 + 64 * (r)), lo); (e).y1 = ldi(opaque_ptr(a.y1 + 64 * (r)), lo); (e).y2 = ldi(opaque_ptr(a.y2 + 64 * (r)), lo); (e).b = ldi(opaque_ptr(a.b + 64 * (r)), lo); }
+#define DDN_CP_LD(r, e) { (e).z = opaque_ptr(a.z + 64 * (r))[lo]; (e).y0 = ldi(opaque_ptr(a.y0 + 64 * (r)), lo); (e).y1 = ldi(opaque_ptr(a.y1 + 64 * (r)), lo); (e).y2 = ldi(opaque_ptr(a.y2 + 64 * (r)), lo); (e).b = opaque_ptr(a.b + 64 * (r))[lo]; }
     float zl = ldi(opaque_ptr(a.z + 64 * (R - 1)), lo);  // last register of the row: z[-1] of lane 0
 #pragma unroll
     for (int g = 0; g < PD; ++g) DDN_CP_LD(g, q[g])
@@ -281,7 +281,7 @@ template <int PD, int SL, int R>
 __device__ __forceinline__ void cp_primalN(cx<float> (&d)[64], const CpArgs<float>& a, int lane, double* partials) {
     struct Q { float x, b, y1, y2; } q[PD];
     const unsigned lo = (unsigned)lane;
-#define DDN_CP_LD(r, e) { (e).x = ldi(opaque_ptr(a.x + 64 * (r)), lo); (e).b = ldi(opaque_ptr(a.b + 64 * (r)), lo); (e).y1 = ldi(opaque_ptr(a.y1 + 64 * (r)), lo); (e).y2 = ldi(opaque_ptr(a.y2 + 64 * (r)), lo); }
+#define DDN_CP_LD(r, e) { (e).x = ldi(opaque_ptr(a.x + 64 * (r)), lo); (e).b = opaque_ptr(a.b + 64 * (r))[lo]; (e).y1 = ldi(opaque_ptr(a.y1 + 64 * (r)), lo); (e).y2 = ldi(opaque_ptr(a.y2 + 64 * (r)), lo); }
 #pragma unroll
     for (int g = 0; g < PD; ++g) DDN_CP_LD(g, q[g])
     double acc[4] = {0, 0, 0, 0};
@@ -294,7 +294,7 @@ __device__ __forceinline__ void cp_primalN(cx<float> (&d)[64], const CpArgs<floa
         const float dd = xn - b_prev;                                             /* cp:96 */  \
         acc[0] += (double)t_abs(dd); acc[1] += (double)dd * (double)dd;                         \
         sti(opaque_ptr(a.x + 64 * (r)), lo, xn);                                                    \
-        sti(opaque_ptr(a.z + 64 * (r)), lo, zn);                                                    \
+        opaque_ptr(a.z + 64 * (r))[lo] = zn;                                                    \
         slot<SL>(d[r]) = zn;                                                                    \
         asm volatile("" : "+v"(slot<SL>(d[r]))); }
 #pragma unroll

@@ -472,7 +472,10 @@ def test_full_size_4096_square_vs_oracle_and_tile_path(pkg, golden_dir, monkeypa
     monkeypatch.setenv("DDN_NO_NYQ_DENSE", "1")
     tiled = run_all(5)
     monkeypatch.delenv("DDN_NO_NYQ_DENSE")
-    for g, r in zip(dense, tiled):
+    # Chambolle-Pock with the dense home evaluates column W/2 as a short correlation along the rows inside the row
+    # kernels (no column transform): the same numbers up to rounding, not bit for bit
+    assert rel(dense[0].numpy(), tiled[0].numpy()) < 1e-6
+    for g, r in zip(dense[1:], tiled[1:]):
         assert np.array_equal(g.numpy(), r.numpy())
 
 

@@ -1,11 +1,11 @@
 """Loss / stop metrics with the reference's signatures (deblur_denoise/core/loss.py).
 l1_loss, l2_loss, mse and psnr are wavefront reductions on the GPU (ddn_reduce); inside the solver
-loops the same four values are produced by the fused row kernels.  ssim (loss.py:39-110) is not yet
-a fused kernel: it is evaluated with torch ops on whatever device its inputs live on."""
+loops the same four values are produced by the fused row kernels.  ssim (loss.py:39-110) is one fused
+device pass (ddn_ssim); inside the solver loops it is evaluated between the launches of an iteration
+without a host round trip (ddn_plan_set_ssim).  There is no host implementation of any of them."""
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from .. import _lib as L
 from ..plan import compute_device, reduce_call
@@ -51,38 +51,38 @@ mse._ddn_kind = L.LOSS_MSE
 psnr._ddn_kind = L.LOSS_PSNR
 
 
+def ssim_window_taps() -> torch.Tensor:
+    """The 11 normalised float32 factors of the reference's Gaussian window (loss.py:75-81), evaluated with the same
+    torch expression so that they agree bit for bit."""
+    co = torch.arange(11, dtype=torch.float32) - 11 // 2
+    g = torch.exp(-(co ** 2) / (2 * 1.5 ** 2))
+    return (g / g.sum()).contiguous()
+
+
 def ssim(x: torch.Tensor, y: torch.Tensor, window_size: int = 11, max_val: float = 1.0) -> torch.Tensor:
-    """SSIM with an 11x11 Gaussian (sigma 1.5) window and zero padding (loss.py:39-110)."""
+    """SSIM with an 11x11 Gaussian (sigma 1.5) window and zero padding (loss.py:39-110): one fused pass over the two
+    images on the GPU (ddn_ssim).  Inputs on the host are staged to the device; the result returns where x lives."""
     def to4(t):
         return t[None, None] if t.dim() == 2 else (t[None] if t.dim() == 3 else t)
     x, y = to4(x), to4(y)
     if x.shape != y.shape:
         raise ValueError(f"Input tensors must have the same shape, got {x.shape} and {y.shape}")
-    if x.is_cuda and y.is_cuda and window_size == 11 and x.dtype == y.dtype and x.dtype in (torch.float32, torch.float64):
-        # fused device kernel (ddn_ssim): one pass over the two images
-        import ctypes as C
-        from ..plan import _ptr
-        B, nc, H, W = x.shape
-        xc, yc = x.contiguous(), y.contiguous()
-        out = torch.empty((B * nc,), dtype=torch.float64, device=x.device)
-        co_ = torch.arange(window_size, dtype=torch.float32) - window_size // 2      # loss.py:75-81, on the host
-        g_ = torch.exp(-(co_ ** 2) / (2 * 1.5 ** 2))
-        g_ = (g_ / g_.sum()).contiguous()
-        g11 = (C.c_float * 11)(*g_.tolist())
-        with torch.cuda.device(x.device):
-            L.check(L.lib().ddn_ssim(L.F64 if x.dtype == torch.float64 else L.F32, _ptr(xc), _ptr(yc), H, W, B * nc, float(max_val), g11, _ptr(out),
-                                     C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
-        return out.view(B, nc).mean(dim=1).to(x.dtype)
-    C1, C2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
-    co = torch.arange(window_size, dtype=torch.float32) - window_size // 2
-    g = torch.exp(-(co ** 2) / (2 * 1.5 ** 2))
-    g = g / g.sum()
-    w = (g[:, None] * g[None, :])[None, None].to(device=x.device, dtype=x.dtype)
-    nc, p = x.shape[1], window_size // 2
-    mu_x = F.conv2d(x, w, padding=p, groups=nc)
-    mu_y = F.conv2d(y, w, padding=p, groups=nc)
-    sx = F.conv2d(x * x, w, padding=p, groups=nc) - mu_x ** 2
-    sy = F.conv2d(y * y, w, padding=p, groups=nc) - mu_y ** 2
-    sxy = F.conv2d(x * y, w, padding=p, groups=nc) - mu_x * mu_y
-    m = ((2 * mu_x * mu_y + C1) * (2 * sxy + C2)) / ((mu_x ** 2 + mu_y ** 2 + C1) * (sx + sy + C2))
-    return m.mean(dim=(2, 3)).mean(dim=1)
+    if window_size != 11:
+        raise L.DdnError("ssim: the fused kernel implements the reference's default 11 x 11 window only")
+    import ctypes as C
+    from ..plan import _ptr
+    src = x.device
+    dt = torch.float64 if x.dtype == torch.float64 else torch.float32
+    dev = compute_device(src)
+    B, nc, H, W = x.shape
+    xc = x.detach().to(device=dev, dtype=dt).contiguous()
+    yc = y.detach().to(device=dev, dtype=dt).contiguous()
+    out = torch.empty((B * nc,), dtype=torch.float64, device=dev)
+    g11 = (C.c_float * 11)(*ssim_window_taps().tolist())
+    with torch.cuda.device(dev):
+        L.check(L.lib().ddn_ssim(L.F64 if dt == torch.float64 else L.F32, _ptr(xc), _ptr(yc), H, W, B * nc, float(max_val), g11, _ptr(out),
+                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out.view(B, nc).mean(dim=1).to(device=src, dtype=dt)
+
+
+ssim._ddn_kind = L.LOSS_SSIM

@@ -160,6 +160,13 @@ struct ddn_plan {
     void* eKc = nullptr;     // column-major natural-order copies of eK and G for the wave-per-column stage
     void* Gcm = nullptr;
     bool eKc_ok = false, Gcm_ok = false;
+    // ssim as the in-loop loss (ddn_plan_set_ssim): window taps, the caller's record, plan-owned scratch
+    float ssim_g[11] = {};
+    double ssim_max = 1.0;
+    double* ssim_ring = nullptr;   // caller-owned [iter][image][2]; null = off
+    double* ssim_part = nullptr;   // per-tile partial sums
+    double* ssim_val = nullptr;    // [batch]
+    void* ssim_prev = nullptr;     // copy of the previous iterate (primal DR compares z1 with z1prev)
     void* nyq_taps = nullptr;  // blur taps transformed along the rows at column W/2 (real, kh entries): see RowCommon::nyq_taps
     int nyq_kh = 0, nyq_ph = 0;
     bool nyq_fir_on = false;   // a Chambolle-Pock loop runs with column W/2 handled by the row kernels
@@ -837,6 +844,23 @@ struct NyqDense {
 };
 
 // ----------------------------------------------------------------------------- solver loops
+// ssim(x, y) of every image -> entry `entry` of iteration `iter`'s slot of the caller's ssim record, and (test) the
+// stop test loss < tol; enqueued on the plan's stream behind the row launch that produced x, no host round trip.
+template <typename T>
+int ssim_step(ddn_plan* p, const void* x, const void* y, int iter, int entry, int clip_x, int first_iter, double tol, bool test) {
+    if (!p->ssim_ring || iter < 1) return DDN_OK;
+    if (!p->ssim_part) HIPCHK(hipMalloc((void**)&p->ssim_part, sizeof(double) * ssim_partial_count(p->H, p->W, p->batch)));
+    if (!p->ssim_val) HIPCHK(hipMalloc((void**)&p->ssim_val, sizeof(double) * (size_t)p->batch));
+    int rc = ssim_launch(sizeof(T) == 8 ? DDN_F64 : DDN_F32, x, y, p->H, p->W, p->batch, p->ssim_max, p->ssim_g, p->ssim_part, p->ssim_val, 1, clip_x, p->stream);
+    if (rc) return rc;
+    double* slot = p->ssim_ring + (size_t)(iter - 1) * p->batch * 2 + entry;
+    return ssim_commit_launch(p->ssim_val, slot, 2, p->stop, p->batch, iter, first_iter, tol, test ? 1 : 0, p->stream);
+}
+inline int need_ssim(const ddn_plan* p, int tol_kind) {
+    if (tol_kind == DDN_LOSS_SSIM && !p->ssim_ring) return fail(DDN_E_STATE, "tol_kind DDN_LOSS_SSIM needs ddn_plan_set_ssim first");
+    return DDN_OK;
+}
+
 template <typename T>
 int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, double rho, double gamma, int objective, int n_iters,
                  int tol_kind, double tol, int first_loss_iter, double* ring, int* iters_done) {
@@ -852,18 +876,28 @@ int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, doubl
     a.z1 = (T*)z1; a.z20 = (T*)z2; a.z21 = (T*)z2 + plane; a.z22 = (T*)z2 + 2 * plane; a.b = (const T*)b;
     a.t = (T)t; a.rho = (T)rho; a.tg = (T)(t * gamma); a.l2div = (T)(2 * t + 1); a.objective = objective;
     int rc;
+    if ((rc = need_ssim(p, tol_kind))) return rc;
+    const bool ssim = tol_kind == DDN_LOSS_SSIM;   // loss_function(z1, z1prev) = ssim: the default of primal_dr/algorithm.py:25
+    const int lk = ssim ? 0 : tol_kind;
+    if (ssim && !p->ssim_prev) HIPCHK(hipMalloc(&p->ssim_prev, plane * sizeof(T)));
     if ((rc = reset_stop<T>(p))) return rc;
     const cx<T>* gc = p->injected ? (const cx<T>*)p->Gc : nullptr;
     if (n_iters > 0) {
         rc0 = row_common<T>(p, cfg.V, false, true);
         if ((rc = launch_solver_row<T, PdrP<T>>(p, cfg, rc0, a))) return rc;
         for (int c = 1; c <= n_iters; ++c) {
-            LossFin lf = make_lf(p, ring, c - 1, tol_kind, tol, first_loss_iter, true);
+            LossFin lf = make_lf(p, ring, c - 1, lk, tol, first_loss_iter, true);
             if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
+            if (ssim) HIPCHK(hipMemcpyAsync(p->ssim_prev, z1, plane * sizeof(T), hipMemcpyDeviceToDevice, p->stream));
             rc0 = row_common<T>(p, cfg.V, true, c < n_iters);
             if ((rc = launch_solver_row<T, PdrP<T>>(p, cfg, rc0, a))) return rc;
+            if (ssim) {
+                if ((rc = ssim_step<T>(p, z1, p->ssim_prev, c, 0, 0, first_loss_iter, tol, true))) return rc;
+                // the reference logs loss_function(z1, b) every 50th iteration (pdr:137-141)
+                if ((c - 1) % 50 == 0 && (rc = ssim_step<T>(p, z1, b, c, 1, 0, 0, 0.0, false))) return rc;
+            }
         }
-        if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, tol_kind, tol, first_loss_iter, true)))) return rc;
+        if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, lk, tol, first_loss_iter, true)))) return rc;
     }
     return finish_iters<T>(p, iters_done, n_iters);
 }
@@ -883,18 +917,22 @@ int pddr_run_impl(ddn_plan* p, void* pp, void* q, const void* b, double t, doubl
     a.p = (T*)pp; a.q0 = (T*)q; a.q1 = (T*)q + plane; a.q2 = (T*)q + 2 * plane; a.b = (const T*)b;
     a.t = (T)t; a.it = (T)(1.0 / t); a.rho = (T)rho; a.itg = (T)((1.0 / t) * gamma);
     int rc;
+    if ((rc = need_ssim(p, tol_kind))) return rc;
+    const bool ssim = tol_kind == DDN_LOSS_SSIM;
+    const int lk = ssim ? 0 : tol_kind;
     if ((rc = reset_stop<T>(p))) return rc;
     const cx<T>* gc = p->injected ? (const cx<T>*)p->Gc : nullptr;
     if (n_iters > 0) {
         rc0 = row_common<T>(p, cfg.V, false, true);
         if ((rc = launch_solver_row<T, PddrP<T>>(p, cfg, rc0, a))) return rc;
         for (int c = 1; c <= n_iters; ++c) {
-            LossFin lf = make_lf(p, ring, c - 1, tol_kind, tol, first_loss_iter, true);
+            LossFin lf = make_lf(p, ring, c - 1, lk, tol, first_loss_iter, true);
             if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
             rc0 = row_common<T>(p, cfg.V, true, c < n_iters);
             if ((rc = launch_solver_row<T, PddrP<T>>(p, cfg, rc0, a))) return rc;
+            if (ssim && (rc = ssim_step<T>(p, pp, b, c, 0, 1, first_loss_iter, tol, true))) return rc;   // loss(clip(p), b), pddr:104
         }
-        if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, tol_kind, tol, first_loss_iter, true)))) return rc;
+        if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, lk, tol, first_loss_iter, true)))) return rc;
     }
     return finish_iters<T>(p, iters_done, n_iters);
 }
@@ -919,6 +957,9 @@ int admm_run_impl(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b
     a.t = (T)t; a.it = (T)(1.0 / t); a.rho = (T)rho; a.omr = (T)(1.0 - rho); a.itg = (T)((1.0 / t) * gamma);
     a.l2div = (T)(2 * (1.0 / t) + 1); a.objective = objective;
     int rc;
+    if ((rc = need_ssim(p, tol_kind))) return rc;
+    const bool ssim = tol_kind == DDN_LOSS_SSIM;
+    const int lk = ssim ? 0 : tol_kind;
     if ((rc = reset_stop<T>(p))) return rc;
     const cx<T>* gc = p->injected ? (const cx<T>*)p->Gc : nullptr;
     // produce the transform inputs of the first solve
@@ -927,20 +968,24 @@ int admm_run_impl(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b
     if ((rc = launch_solver_row<T, AdmmP<T>>(p, cfg, rc0, a))) return rc;
     for (int c = 1; c <= n_iters; ++c) {
         // partial sums written by call c-1 describe sol of iteration c-2
-        LossFin lf = make_lf(p, ring, c - 2, tol_kind, tol, first_loss_iter, true);
+        LossFin lf = make_lf(p, ring, c - 2, lk, tol, first_loss_iter, true);
         if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
         rc0 = row_common<T>(p, cfg.V, true, true);
         a.sol = (tol_kind > 0) ? (T*)sol : nullptr;
         if ((rc = launch_solver_row<T, AdmmP<T>>(p, cfg, rc0, a))) return rc;
+        // launch c stored the look-ahead solution of iteration c - 1 (admm:118-139)
+        if (ssim && (rc = ssim_step<T>(p, sol, b, c - 1, 0, 0, first_loss_iter, tol, true))) return rc;
     }
     {
-        LossFin lf = make_lf(p, ring, n_iters - 1, tol_kind, tol, first_loss_iter, true);
+        LossFin lf = make_lf(p, ring, n_iters - 1, lk, tol, first_loss_iter, true);
         if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
         rc0 = row_common<T>(p, cfg.V, true, false);
         a.sol = (T*)sol; a.sol_only = 1;
         if ((rc = launch_solver_row<T, AdmmP<T>>(p, cfg, rc0, a))) return rc;
-        if (n_iters >= 1)
-            if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, tol_kind, tol, first_loss_iter, true)))) return rc;
+        if (n_iters >= 1) {
+            if (ssim && (rc = ssim_step<T>(p, sol, b, n_iters, 0, 0, first_loss_iter, tol, true))) return rc;
+            if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, lk, tol, first_loss_iter, true)))) return rc;
+        }
     }
     return finish_iters<T>(p, iters_done, n_iters);
 }
@@ -996,6 +1041,7 @@ int cp_run_impl(ddn_plan* p, void* x, void* z, void* y, const void* b, double t,
             rc0.stop = nullptr;
             with_fir(rc0, -1);    // consumes K^T y0
             if ((rc = launch_cp_row<T>(p, cfg, rc0, a))) return rc;
+            if (p->ssim_ring && (rc = ssim_step<T>(p, x, b, c, 0, 0, 0, 0.0, false))) return rc;   // loss(x_next, b), cp:96
         }
         if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, 0, 0.0, 1, false)))) return rc;
     }
@@ -1063,9 +1109,7 @@ int slab_rows_impl(ddn_plan* p, int solver, int rows, void* spec, void* s0, void
     const bool al = aligned16(s0) && aligned16(s1) && (!s2 || aligned16(s2)) && (!s3 || aligned16(s3)) && aligned16(b) && (!sol || aligned16(sol)) &&
                     ((plane * sizeof(T)) % 16 == 0);
     if (!row_cfg<T>(p, al, rows, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
-    int rc;
-    if ((rc = reset_stop<T>(p))) return rc;
-    RowCommon<T> c = row_common<T>(p, cfg.V, consume != 0, produce != 0);
+    RowCommon<T> c = row_common<T>(p, cfg.V, consume != 0, produce != 0);   // c.stop: the plan's flag, see ddn_slab_begin / ddn_slab_stop_test
     const size_t C = (size_t)1 << p->cs;
     c.S0 = (cx<T>*)spec;
     c.S1 = (cx<T>*)spec + (size_t)rows * C;
@@ -1206,6 +1250,39 @@ int slab_rows_cp_impl(ddn_plan* p, int rows, void* spec, void* spec_aux, void* x
     return launch_cp_row<T>(p, cfg, c, a);
 }
 
+// raw loss sums of a slab's rows: sum |d| and sum d^2 of the primary pair, then of the secondary pair
+__global__ void k_slab_sums(const double* partials, int rows, double* sums4) {
+    __shared__ double red[16 * 4];
+    double v[4] = {0, 0, 0, 0};
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] += partials[(size_t)r * 4 + s];
+    }
+    block_reduce<4>(v, red, threadIdx.x, blockDim.x);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sums4[s] = v[s];
+    }
+}
+// whole-image record and stop test from the sums over all slabs (the same arithmetic as loss_finalize)
+__global__ void k_slab_stop_test(const double* sums4, int kind, double tol, int iter, int first_iter, double npix, int* stop, double* record8) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (stop[0] >= 0) return;  // frozen: keeps its last record
+    double out[8];
+    for (int h = 0; h < 2; ++h) {
+        const double s1 = sums4[2 * h], s2 = sums4[2 * h + 1];
+        const double mse = s2 / npix;
+        out[4 * h + 0] = s1;
+        out[4 * h + 1] = sqrt(s2);
+        out[4 * h + 2] = mse;
+        out[4 * h + 3] = (mse == 0.0) ? (double)INFINITY : 10.0 * log10(1.0 / mse);
+    }
+    if (record8) {
+        for (int i = 0; i < 8; ++i) record8[i] = out[i];
+    }
+    if (kind >= 1 && kind <= 4 && iter >= first_iter && out[kind - 1] < tol) stop[0] = iter;
+}
+
 }  // namespace
 
 // ------------------------------------------------- scratch of the allocation-free entry point
@@ -1286,7 +1363,7 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
 
 int ddn_plan_destroy(ddn_plan* p) {
     if (!p) return DDN_OK;
-    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->nyqd, p->nyq_taps, p->eKc, p->ctab, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
+    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->nyqd, p->ssim_part, p->ssim_val, p->ssim_prev, p->nyq_taps, p->eKc, p->ctab, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : p->ev_pool) {
@@ -1387,6 +1464,19 @@ int ddn_plan_set_resolvent(ddn_plan* p, double cK, double cD, const void* M_dev,
     if (!p) return fail(DDN_E_ARG, "null plan");
     if (p->injected && !M_dev) return fail(DDN_E_ARG, "set_resolvent: injected eigen arrays need the injected eig_vals_mat too");
     return p->dtype == DDN_F32 ? set_resolvent_impl<float>(p, cK, cD, M_dev, cdtype) : set_resolvent_impl<double>(p, cK, cD, M_dev, cdtype);
+}
+
+int ddn_plan_set_ssim(ddn_plan* p, const float* g11_host, double max_val, double* ssim_ring_dev) {
+    if (!p) return fail(DDN_E_ARG, "null plan");
+    if (!ssim_ring_dev) {
+        p->ssim_ring = nullptr;
+        return DDN_OK;
+    }
+    if (!g11_host) return fail(DDN_E_ARG, "set_ssim: window taps missing");
+    for (int i = 0; i < 11; ++i) p->ssim_g[i] = g11_host[i];
+    p->ssim_max = max_val;
+    p->ssim_ring = ssim_ring_dev;
+    return DDN_OK;
 }
 
 int ddn_plan_get_eigK(ddn_plan* p, void* out_dev) {
@@ -1583,6 +1673,34 @@ int ddn_slab_loss(ddn_plan* p, int rows, double* record8) {
     lf.enabled = 1;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, p->stream, lf);
     HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+int ddn_slab_begin(ddn_plan* p) {
+    if (!p) return fail(DDN_E_ARG, "slab_begin: null plan");
+    HIPCHK(hipMemsetAsync(p->stop, 0xff, (size_t)p->batch * sizeof(int), p->stream));
+    return DDN_OK;
+}
+
+int ddn_slab_loss_sums(ddn_plan* p, int rows, double* sums4) {
+    if (!p || !sums4) return fail(DDN_E_ARG, "slab_loss_sums: null argument");
+    if (p->batch != 1 || rows < 1 || rows > p->H) return fail(DDN_E_ARG, "slab_loss_sums: bad arguments");
+    hipLaunchKernelGGL(k_slab_sums, dim3(1), dim3(256), 0, p->stream, (const double*)p->partials, rows, sums4);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+int ddn_slab_stop_test(ddn_plan* p, const double* sums4, int kind, double tol, int iter, int first_iter, double* record8) {
+    if (!p || !sums4) return fail(DDN_E_ARG, "slab_stop_test: null argument");
+    if (kind < 0 || kind > 4) return fail(DDN_E_ARG, "slab_stop_test: loss kind must be one of DDN_LOSS_NONE .. DDN_LOSS_PSNR");
+    hipLaunchKernelGGL(k_slab_stop_test, dim3(1), dim3(1), 0, p->stream, sums4, kind, tol, iter, first_iter, (double)p->H * (double)p->W, p->stop, record8);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+int ddn_slab_iters_done(ddn_plan* p, int* done_dev) {
+    if (!p || !done_dev) return fail(DDN_E_ARG, "slab_iters_done: null argument");
+    HIPCHK(hipMemcpyAsync(done_dev, p->stop, sizeof(int), hipMemcpyDeviceToDevice, p->stream));
     return DDN_OK;
 }
 

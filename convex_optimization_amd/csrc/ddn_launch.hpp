@@ -8,6 +8,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <utility>
 
 #include "../../include/ddn.h"
 #include "ddn_kernels.hpp"
@@ -30,13 +31,16 @@ inline int fail(int code, const std::string& msg) {
 
 constexpr size_t kLdsMax = 160 * 1024;
 
+// The attribute is set once per (device, kernel): a process that drives several GPUs loads the code object on each.
 inline int ensure_lds_attr(const void* fn) {
     static std::mutex mu;
-    static std::set<const void*> done;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    if (done.count(fn)) return DDN_OK;
+    if (done.count({dev, fn})) return DDN_OK;
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
-    done.insert(fn);
+    done.insert({dev, fn});
     return DDN_OK;
 }
 
@@ -71,6 +75,12 @@ int wrown_cp_launch(hipStream_t st, int grid, const RowCommon<float>& c, const C
 int wcol_launch(hipStream_t st, int mode, const wcol::Args& a);
 // The same for H = 512, 1024, 2048 (several adjacent columns per wavefront; ddn_wcoln.hpp), in ddn_wcoln.hip.
 int wcoln_launch(hipStream_t st, int mode, const wcol::Args& a);
+
+// SSIM (core/loss.py:39-110) without allocation or synchronisation, for use inside the solver loops (ddn_ssim.hip)
+size_t ssim_partial_count(int H, int W, int planes);
+int ssim_launch(int dtype, const void* x, const void* y, int H, int W, int planes, double max_val, const float* g11, double* partial_dev, double* out_dev,
+                int out_stride, int clip_x, hipStream_t st);
+int ssim_commit_launch(const double* value, double* slot, int slot_stride, int* stop, int batch, int iter, int first_iter, double tol, int test, hipStream_t st);
 
 template <typename T, class P>
 int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const RowCommon<T>& c, const typename P::Args& a) {

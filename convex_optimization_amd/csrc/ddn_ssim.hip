@@ -16,7 +16,7 @@ struct SsimWin {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_ssim_tile(const T* x, const T* y, int H, int W, int tiles_x, int tiles_y, SsimWin win, double c1, double c2, double* partial) {
+__global__ void __launch_bounds__(256) k_ssim_tile(const T* x, const T* y, int H, int W, int tiles_x, int tiles_y, SsimWin win, double c1, double c2, double* partial, int clip_x) {
     __shared__ T sx[PH][PW + 1], sy[PH][PW + 1];
     __shared__ T hm[5][PH][TW + 1];
     __shared__ double red[64];
@@ -33,7 +33,9 @@ __global__ void __launch_bounds__(256) k_ssim_tile(const T* x, const T* y, int H
         const int pr = i / PW, pc = i - pr * PW;
         const int r = r0 + pr, c = c0 + pc;
         const bool in = r >= 0 && r < H && c >= 0 && c < W;
-        sx[pr][pc] = in ? xp[(size_t)r * W + c] : (T)0;
+        T vx0 = in ? xp[(size_t)r * W + c] : (T)0;
+        if (clip_x) vx0 = vx0 < (T)0 ? (T)0 : (vx0 > (T)1 ? (T)1 : vx0);   // the solver's clip(p) (primal_dual_dr/algorithm.py:104)
+        sx[pr][pc] = vx0;
         sy[pr][pc] = in ? yp[(size_t)r * W + c] : (T)0;
     }
     __syncthreads();
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(256) k_ssim_tile(const T* x, const T* y, int H
     if (tid == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void k_ssim_final(const double* partial, int per_plane, double npix, double* out) {
+__global__ void k_ssim_final(const double* partial, int per_plane, double npix, double* out, int out_stride) {
     __shared__ double red[256];
     const int plane = blockIdx.x, tid = threadIdx.x;
     double a = 0;
@@ -120,7 +122,7 @@ __global__ void k_ssim_final(const double* partial, int per_plane, double npix, 
         if (tid < s) red[tid] += red[tid + s];
         __syncthreads();
     }
-    if (tid == 0) out[plane] = red[0] / npix;
+    if (tid == 0) out[(size_t)plane * out_stride] = red[0] / npix;
 }
 
 // X^T w for the k x k blind-kernel step (op_math/python_code/apply_x_trans.py:4-46), k odd:
@@ -145,7 +147,48 @@ __global__ void k_apply_x_trans(const T* __restrict__ w, const T* __restrict__ x
     out[idx] = (T)acc;
 }
 
+// In-loop use: value[image] -> this iteration's slot of the caller's record, and the stop test, unless the image is
+// already frozen (it keeps its last record, as with the other loss kinds).
+__global__ void k_ssim_commit(const double* value, double* slot, int slot_stride, int* stop, int batch, int iter, int first_iter, double tol, int test) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    if (stop && stop[i] >= 0) return;
+    const double v = value[i];
+    slot[(size_t)i * slot_stride] = v;
+    if (test && stop && iter >= first_iter && v < tol) stop[i] = iter;
+}
+
 }  // namespace
+
+size_t ssim_partial_count(int H, int W, int planes) {
+    return (size_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH) * planes;
+}
+
+// The two SSIM kernels on `st`, no allocation, no synchronisation: partial_dev holds ssim_partial_count doubles,
+// out_dev[plane * out_stride] receives the mean SSIM of each plane.
+int ssim_launch(int dtype, const void* x, const void* y, int H, int W, int planes, double max_val, const float* g11, double* partial_dev, double* out_dev,
+                int out_stride, int clip_x, hipStream_t st) {
+    SsimWin win;
+    for (int i = 0; i < 11; ++i) win.g[i] = g11[i];
+    for (int i = 0; i < 11; ++i)
+        for (int j = 0; j < 11; ++j) win.w2[i * 11 + j] = g11[i] * g11[j];  // float32 product, as g[:, None] * g[None, :]
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int per_plane = tiles_x * tiles_y;
+    const double c1 = (0.01 * max_val) * (0.01 * max_val), c2 = (0.03 * max_val) * (0.03 * max_val);
+    if (dtype == DDN_F32)
+        hipLaunchKernelGGL(k_ssim_tile<float>, dim3(per_plane * planes), dim3(256), 0, st, (const float*)x, (const float*)y, H, W, tiles_x, tiles_y, win, c1, c2, partial_dev, clip_x);
+    else
+        hipLaunchKernelGGL(k_ssim_tile<double>, dim3(per_plane * planes), dim3(256), 0, st, (const double*)x, (const double*)y, H, W, tiles_x, tiles_y, win, c1, c2, partial_dev, clip_x);
+    hipLaunchKernelGGL(k_ssim_final, dim3(planes), dim3(256), 0, st, partial_dev, per_plane, (double)H * (double)W, out_dev, out_stride);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+int ssim_commit_launch(const double* value, double* slot, int slot_stride, int* stop, int batch, int iter, int first_iter, double tol, int test, hipStream_t st) {
+    hipLaunchKernelGGL(k_ssim_commit, dim3((batch + 63) / 64), dim3(64), 0, st, value, slot, slot_stride, stop, batch, iter, first_iter, tol, test);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
 
 extern "C" int ddn_apply_x_trans(int dtype, const void* w_dev, const void* x_dev, int kernel_size, void* out_dev, void* stream) {
     if (!w_dev || !x_dev || !out_dev || kernel_size < 1) return fail(DDN_E_ARG, "apply_x_trans: bad arguments");
@@ -163,22 +206,12 @@ extern "C" int ddn_apply_x_trans(int dtype, const void* w_dev, const void* x_dev
 extern "C" int ddn_ssim(int dtype, const void* x, const void* y, int H, int W, int planes, double max_val, const float* g11_host, double* out_dev, void* stream) {
     if (!x || !y || !out_dev || !g11_host || H < 1 || W < 1 || planes < 1) return fail(DDN_E_ARG, "ssim: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    SsimWin win;
-    for (int i = 0; i < 11; ++i) win.g[i] = g11_host[i];
-    for (int i = 0; i < 11; ++i)
-        for (int j = 0; j < 11; ++j) win.w2[i * 11 + j] = g11_host[i] * g11_host[j];  // float32 product, as g[:, None] * g[None, :]
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int per_plane = tiles_x * tiles_y;
     double* part = nullptr;
-    HIPCHK(hipMalloc((void**)&part, sizeof(double) * (size_t)per_plane * planes));
-    const double c1 = (0.01 * max_val) * (0.01 * max_val), c2 = (0.03 * max_val) * (0.03 * max_val);
-    if (dtype == DDN_F32)
-        hipLaunchKernelGGL(k_ssim_tile<float>, dim3(per_plane * planes), dim3(256), 0, st, (const float*)x, (const float*)y, H, W, tiles_x, tiles_y, win, c1, c2, part);
-    else
-        hipLaunchKernelGGL(k_ssim_tile<double>, dim3(per_plane * planes), dim3(256), 0, st, (const double*)x, (const double*)y, H, W, tiles_x, tiles_y, win, c1, c2, part);
-    hipLaunchKernelGGL(k_ssim_final, dim3(planes), dim3(256), 0, st, part, per_plane, (double)H * (double)W, out_dev);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMalloc((void**)&part, sizeof(double) * ssim_partial_count(H, W, planes)));
+    const int rc = ssim_launch(dtype, x, y, H, W, planes, max_val, g11_host, part, out_dev, 1, 0, st);
+    const hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(part);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(DDN_E_HIP, hipGetErrorString(e));
     return DDN_OK;
 }

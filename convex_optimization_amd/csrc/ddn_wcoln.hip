@@ -7,7 +7,7 @@ template <int MODE, int R, int NP, bool ILV = false, bool RB = false>
 static int wcoln_go1(hipStream_t st, const wcol::Args& a) {
     constexpr int waves = (MODE == COL_RES2 ? 2 : 1) * NP;
     constexpr int M = 64 / R;
-    if ((1 << a.lay.cs) < M * NP || a.lay.cs > 4) return DDN_E_UNSUPPORTED;
+    if ((1 << a.lay.cs) < M * NP || a.lay.cs > 4) return fail(DDN_E_UNSUPPORTED, "wcoln: the spectral tile width does not hold a whole column group");
     const int G = (1 << a.lay.cs) / (M * NP);
     auto fn = wcol::k_wave_colN<MODE, R, NP, ILV, RB>;
     int rc = ensure_lds_attr((const void*)fn);
@@ -26,7 +26,7 @@ static int wcoln_go(hipStream_t st, const wcol::Args& a) {
     constexpr int M = 64 / R;
     if (a.rb_extra) {
         // rows stored in per-source blocks (row-slab decomposition): separate spectra, one group per workgroup
-        if (a.ilv) return DDN_E_UNSUPPORTED;
+        if (a.ilv) return fail(DDN_E_UNSUPPORTED, "wcoln: row blocks go with separate spectra");
         return wcoln_go1<MODE, R, 1, false, true>(st, a);
     }
     if constexpr (MODE == COL_RES2) {
@@ -46,6 +46,6 @@ int wcoln_launch(hipStream_t st, int mode, const wcol::Args& a) {
         case 512: return res ? wcoln_go<COL_RES2, 8>(st, a) : wcoln_go<COL_MUL, 8>(st, a);
         case 1024: return res ? wcoln_go<COL_RES2, 16>(st, a) : wcoln_go<COL_MUL, 16>(st, a);
         case 2048: return res ? wcoln_go<COL_RES2, 32>(st, a) : wcoln_go<COL_MUL, 32>(st, a);
-        default: return DDN_E_UNSUPPORTED;
+        default: return fail(DDN_E_UNSUPPORTED, "wcoln: column length is not 512, 1024 or 2048");
     }
 }

@@ -96,7 +96,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // moves both spectra of a frequency with one 16-byte access, and the column stage, whose workgroup
 // owns 4 columns of both spectra, finds them in 64 contiguous bytes of a row instead of 2 x 32.
 template <bool TWO, bool ILV = false>
-__device__ __forceinline__ void pack(cx<float> (&d)[64], const cx<float>* rowA, const cx<float>* rowB, const SpecAddr& sa, int lane, const float* nyqA = nullptr, const float* nyqB = nullptr) {
+__device__ __forceinline__ void pack(cx<float> (&d)[64], const cx<float>* rowA, const cx<float>* rowB, const SpecAddr& sa, int lane, const float* nyqA = nullptr, const float* nyqB = nullptr,
+                                     bool nyq_vals = false, float nyq_a = 0.f, float nyq_b = 0.f) {
+    // nyq_vals: the two column-W/2 terms are handed in as values (computed by the caller) instead of being read
     cx<float> Un, Vn;
     if (ILV) {
         const f4* const q = reinterpret_cast<const f4*>(rowA);
@@ -121,8 +123,13 @@ __device__ __forceinline__ void pack(cx<float> (&d)[64], const cx<float>* rowA, 
             d[63 - r] = TWO ? (rowB + r * sa.rstride)[sa.lane_off] : mk<float>(0.f, 0.f);  // B[k]
         }
         // column W/2 (real): from its dense home when there is one, else from the last tile
-        Un = nyqA ? mk<float>(*nyqA, 0.f) : rowA[sa.nyq];
-        Vn = TWO ? (nyqB ? mk<float>(*nyqB, 0.f) : rowB[sa.nyq]) : mk<float>(0.f, 0.f);
+        if (nyq_vals) {
+            Un = mk<float>(nyq_a, 0.f);
+            Vn = mk<float>(TWO ? nyq_b : 0.f, 0.f);
+        } else {
+            Un = nyqA ? mk<float>(*nyqA, 0.f) : rowA[sa.nyq];
+            Vn = TWO ? (nyqB ? mk<float>(*nyqB, 0.f) : rowB[sa.nyq]) : mk<float>(0.f, 0.f);
+        }
     }
     sched_fence();
     const int ml = (64 - lane) & 63;
@@ -457,10 +464,8 @@ __global__ void __launch_bounds__(64 * WPW, 2) k_wave_cp(RowCommon<float> c, CpA
                 un *= c.nyq_scale;
                 vn *= c.nyq_scale;
             }
-            const float* const pa = fir ? &un : nqa;
-            const float* const pb = fir ? &vn : nqb;
-            if (two) pack<true>(d, rw0, rw1, sa, lane, pa, pb);
-            else pack<false>(d, rw0, nullptr, sa, lane, pa, nullptr);
+            if (two) pack<true>(d, rw0, rw1, sa, lane, nqa, nqb, fir, un, vn);
+            else pack<false>(d, rw0, nullptr, sa, lane, nqa, nullptr, fir, un, vn);
             wfft::fft4096<true>(d, c.wtw, tile, lane);
             pin(d);
         } else {

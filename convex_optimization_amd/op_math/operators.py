@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
-from ..plan import Plan, compute_device, real_dtype, stage
+from ..plan import Plan, acquire_plan, compute_device, plan_key, real_dtype, release_plan, stage
 
 
 def _ctype(dt):
@@ -72,11 +72,19 @@ class DeblurDenoiseOperators:
         self._dt = real_dtype(kwargs.get("dtype", blurred_image.dtype if isinstance(blurred_image, torch.Tensor) else torch.float32))
         self._dev = compute_device(device if device != "cpu" else (blurred_image.device if isinstance(blurred_image, torch.Tensor) else None))
         self._batch = int(kwargs.get("batch", 1))
-        self.plan = Plan(self.num_rows, self.num_cols, self._batch, self._dt, self._dev, tune=kwargs.get("tune"))
         self._plan1: Optional[Plan] = None
         self._eig_arrays = kwargs.get("eig_arrays")
         self._cache = {}
-        self.setup_operators()
+        # plans built from a blur kernel (not from injected eigen arrays) are reused across calls: see plan.py
+        key = None
+        if self._eig_arrays is None:
+            cK = float(self.t) * float(self.t)
+            key = plan_key(self.num_rows, self.num_cols, self._batch, self._dt, self._dev, kernel, cK, cK + float(self.t) * float(self.s), kwargs.get("tune"))
+        self.plan = acquire_plan(key) if key is not None else None
+        if self.plan is None:
+            self.plan = Plan(self.num_rows, self.num_cols, self._batch, self._dt, self._dev, tune=kwargs.get("tune"))
+            self.plan.cache_key = key
+            self.setup_operators()
 
     # mm:48-72
     def setup_operators(self):
@@ -175,6 +183,9 @@ class DeblurDenoiseOperators:
     def invert_matrix(self, x): return self._apply(L.OP_RESOLVENT, x)
 
     def close(self):
-        self.plan.close()
+        if self.plan is not None:
+            release_plan(self.plan)
+            self.plan = None
         if self._plan1 is not None:
             self._plan1.close()
+            self._plan1 = None

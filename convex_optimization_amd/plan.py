@@ -2,6 +2,8 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
+from collections import OrderedDict
 from typing import Optional
 
 import numpy as np
@@ -57,8 +59,10 @@ class Plan:
             L.check(L.lib().ddn_plan_create(C.byref(self._h), self.H, self.W, self.batch,
                                             L.F64 if dtype == torch.float64 else L.F32, C.c_void_p(stream)))
             if tune:
-                L.check(L.lib().ddn_plan_tune(self._h, int(tune.get("cols", 0)), int(tune.get("split", 0)), int(tune.get("row_threads", 0))))
+                L.check(L.lib().ddn_plan_tune(self._h, int(tune.get("cols", 0)), int(tune.get("split", 0)),
+                                              int(tune.get("col_threads", tune.get("row_threads", 0)))))
         self._keep = []
+        self.cache_key = None
 
     def close(self):
         if self._h and self._h.value:
@@ -107,6 +111,15 @@ class Plan:
                 torch.cuda.synchronize(self.dev)
             else:
                 L.check(L.lib().ddn_plan_set_resolvent(self._h, float(cK), float(cD), C.c_void_p(0), 0))
+
+    def set_ssim(self, ring: Optional[torch.Tensor], max_val: float = 1.0):
+        """ssim as the in-loop loss of the following *_run calls: ring = float64 device tensor [iters][batch][2], or None = off."""
+        from .core.loss import ssim_window_taps
+        if ring is None:
+            L.check(L.lib().ddn_plan_set_ssim(self._h, None, 0.0, C.c_void_p(0)))
+            return
+        g11 = (C.c_float * 11)(*ssim_window_taps().tolist())
+        L.check(L.lib().ddn_plan_set_ssim(self._h, g11, float(max_val), _ptr(ring)))
 
     def get_eigK(self) -> torch.Tensor:
         ct = torch.complex128 if self.dtype == torch.float64 else torch.complex64
@@ -165,3 +178,59 @@ def reduce_call(x: torch.Tensor, y: torch.Tensor, batch: int = 1) -> torch.Tenso
         L.check(L.lib().ddn_reduce(L.F64 if x.dtype == torch.float64 else L.F32, _ptr(x), _ptr(y), x.numel() // batch, batch, _ptr(out),
                                    C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
     return out
+
+
+# ---- plan cache ---------------------------------------------------------------------------------
+# A plan owns the spectral scratch, the twiddle tables and the multipliers of one (size, batch, dtype, blur kernel,
+# resolvent coefficients) combination: about 0.6 GB and a few milliseconds of set-up at 4096 x 4096.  Solver calls
+# in a loop (deblur_image per frame, parameter sweeps) repeat that combination, so plans that a caller releases are
+# parked here and handed to the next caller with the same key instead of being rebuilt.  A parked plan is owned by
+# nobody; acquire removes it from the cache, so two live users never share one.  DDN_PLAN_CACHE=<n> sets the number
+# of parked plans (default 2, 0 = off).
+_PLAN_CACHE: "OrderedDict[tuple, Plan]" = OrderedDict()
+_CACHE_STATS = {"hits": 0, "misses": 0}
+
+
+def _cache_capacity() -> int:
+    try:
+        return max(0, int(os.environ.get("DDN_PLAN_CACHE", "2")))
+    except ValueError:
+        return 2
+
+
+def plan_key(H, W, batch, dtype, dev, kernel, cK, cD, tune):
+    k = taps_array(kernel)
+    tk = tuple(sorted((tune or {}).items()))
+    return (int(H), int(W), int(batch), str(dtype), str(dev), k.shape, k.tobytes(), float(cK), float(cD), tk)
+
+
+def acquire_plan(key):
+    """A parked plan with this key (its kernel and resolvent are already set), or None."""
+    pl = _PLAN_CACHE.pop(key, None)
+    _CACHE_STATS["hits" if pl is not None else "misses"] += 1
+    return pl
+
+
+def release_plan(plan: "Plan"):
+    """Parks a plan for reuse (or destroys it when it has no key or the cache is off)."""
+    cap = _cache_capacity()
+    if plan.cache_key is None or cap == 0 or not (plan._h and plan._h.value):
+        plan.close()
+        return
+    old = _PLAN_CACHE.pop(plan.cache_key, None)
+    if old is not None and old is not plan:
+        old.close()
+    _PLAN_CACHE[plan.cache_key] = plan
+    while len(_PLAN_CACHE) > cap:
+        _, victim = _PLAN_CACHE.popitem(last=False)
+        victim.close()
+
+
+def clear_plan_cache():
+    while _PLAN_CACHE:
+        _, pl = _PLAN_CACHE.popitem()
+        pl.close()
+
+
+def plan_cache_stats():
+    return dict(_CACHE_STATS, parked=len(_PLAN_CACHE))

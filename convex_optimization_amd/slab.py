@@ -19,8 +19,12 @@ power of two), so neither side repacks anything; for other row counts one stride
 receiving side builds [2][local tiles][H][C] instead.
 
 Loss records add up over ranks: every rank finalises the sums of its own rows, the sums of |d| and
-d^2 are all-reduced once per solve, and l2 / mse / psnr are recomputed from the totals.  There is
-no early stop in the slab loops (the reference's `break` needs the global loss every iteration).
+d^2 are all-reduced, and l2 / mse / psnr are recomputed from the totals.  Without a loss_function that
+happens once per solve.  With loss_function = l1_loss / l2_loss / mse / psnr of this package (and tol) the
+reference's early stop (admm:152-154, pdr:159-161, pddr:119-121) is reproduced: after every iteration the
+four local sums are all-reduced (32 bytes, enqueued on the stream like the exchanges: no host round trip),
+every rank evaluates the same stop test on the device and a set flag freezes the iterates of all ranks at the
+reference's iteration; the host looks at the flag every `check_every` iterations to leave its launch loop.
 """
 from __future__ import annotations
 
@@ -172,6 +176,9 @@ class SlabSolver:
         self.lay = SlabLayout(H, W, c.value, n.value, self.rank, self.world)
         self.xch = SlabExchange(self.lay, torch.complex128 if self.dt == torch.float64 else torch.complex64, self.dev, group, n_spectra)
         self._rec = torch.zeros((8,), dtype=torch.float64, device=self.dev)
+        self._sums = torch.zeros((4,), dtype=torch.float64, device=self.dev)
+        self._done = torch.full((1,), -1, dtype=torch.int32, device=self.dev)
+        L.check(L.lib().ddn_slab_begin(self.plan._h))
 
     def close(self):
         self.plan.close()
@@ -206,10 +213,51 @@ class SlabSolver:
                                                          self.xch.n_row_blocks))
         self.xch.cols_to_rows()
 
+    def stop_test(self, kind: int, tol: float, it: int, first_it: int, record: Optional[torch.Tensor]):
+        """Whole-image loss record of the last consuming row launch into `record` ([8], may be None) and the stop test
+        `loss < tol` on the device: local sums -> all-reduce (SUM) of four doubles -> every rank decides alike."""
+        from .plan import _ptr
+        self.L.check(self.L.lib().ddn_slab_loss_sums(self.plan._h, self.lay.rows, _ptr(self._sums)))
+        if self.world > 1:
+            if dist.get_backend(self.group) == "gloo" and self._sums.is_cuda:
+                h = self._sums.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                self._sums.copy_(h)
+            else:
+                dist.all_reduce(self._sums, op=dist.ReduceOp.SUM, group=self.group)
+        self.L.check(self.L.lib().ddn_slab_stop_test(self.plan._h, _ptr(self._sums), int(kind), float(tol), int(it), int(first_it), _ptr(record)))
+
+    def stopped_at(self) -> int:
+        """-1 while running, else the iteration at which the device froze the solve (reads one int: a host sync)."""
+        from .plan import _ptr
+        self.L.check(self.L.lib().ddn_slab_iters_done(self.plan._h, _ptr(self._done)))
+        return int(self._done.item())
+
     def loss_record(self, out: torch.Tensor):
         """out[8] <- the loss sums of the local rows seen by the last consuming row launch."""
         from .plan import _ptr
         self.L.check(self.L.lib().ddn_slab_loss(self.plan._h, self.lay.rows, _ptr(out)))
+
+
+def _stop_args(kwargs):
+    """(kind, tol, check_every) of the optional early stop: loss_function must be one of this package's l1_loss, l2_loss,
+    mse, psnr (their sums add up over slabs); ssim and arbitrary callables need the whole image and are refused."""
+    fn = kwargs.get("loss_function")
+    if fn is None:
+        return 0, 0.0, 0
+    kind = int(getattr(fn, "_ddn_kind", 0))
+    if not 1 <= kind <= 4:
+        raise ValueError("slab solvers: loss_function must be l1_loss, l2_loss, mse or psnr of convex_optimization_amd.core")
+    return kind, float(kwargs.get("tol", 1e-6)), max(1, int(kwargs.get("check_every", 10)))
+
+
+def _finish_records(sv, ring, n, kind, H, W, group):
+    """(records of the iterations applied, iterations applied)."""
+    if kind:
+        st = sv.stopped_at()
+        nd = n if st < 0 else st
+        return ring[:nd].cpu(), nd
+    return combine_loss_records(ring[:n], float(H) * float(W), group).cpu(), n
 
 
 def _local_rows(full: torch.Tensor, lay: SlabLayout) -> torch.Tensor:
@@ -220,7 +268,8 @@ def admm_solver_slab(b_rows: torch.Tensor, image_shape: Tuple[int, int], objecti
                      gamma: float = 0.5, kernel=None, niters: int = 500, **kwargs):
     """admm_solver (admm/algorithm.py:20-201) for one image whose rows are spread over the ranks of
     `group`.  b_rows: this rank's (H / P, W) rows of the blurred image.  Returns this rank's rows of the
-    solution of the final solve (admm:160-173).  Runs niters - 1 iterations; no early stop.
+    solution of the final solve (admm:160-173).  Runs up to niters - 1 iterations; with loss_function (l1_loss, l2_loss,
+    mse or psnr of this package), tol and check_every it stops where the reference does (admm:139-154).
 
     Keyword extensions: init_state = (u, w, y, z) local slabs ((rows, W) and (3, rows, W)); without it
     the reference's draws (admm:49-54) are made for the WHOLE image on every rank from torch's CPU
@@ -253,33 +302,52 @@ def admm_solver_slab(b_rows: torch.Tensor, image_shape: Tuple[int, int], objecti
         with torch.cuda.device(dev):
             sv.plan.sync_stream()
             st = (u, w, y, z)
+            kind, tol, every = _stop_args(kwargs)
             sv.rows(SOLVER_ADMM, st, bd, t, rho, gamma, obj, False, True)
+            stopped = False
             for c in range(1, n + 1):
                 sv.column_stage()
-                sv.rows(SOLVER_ADMM, st, bd, t, rho, gamma, obj, True, True)
+                # with a stop test every consuming launch stores the look-ahead solution, so that the one of the stopping
+                # iteration is what `sol` holds when the flag freezes the rows (admm:118-154)
+                sv.rows(SOLVER_ADMM, st, bd, t, rho, gamma, obj, True, True, sol=sol if kind else None)
                 if c >= 2:
-                    sv.loss_record(ring[c - 2])   # the look-ahead solution of iteration c - 1 (admm:118-139)
-            sv.column_stage()
-            sv.rows(SOLVER_ADMM, st, bd, t, rho, gamma, obj, True, False, sol=sol, sol_only=True)
-            if n >= 1:
-                sv.loss_record(ring[n - 1])
+                    if kind:
+                        sv.stop_test(kind, tol, c - 1, 2, ring[c - 2])
+                        if c % every == 0 and sv.stopped_at() >= 0:
+                            stopped = True
+                            break
+                    else:
+                        sv.loss_record(ring[c - 2])   # the look-ahead solution of iteration c - 1 (admm:118-139)
+            if not stopped:
+                sv.column_stage()
+                sv.rows(SOLVER_ADMM, st, bd, t, rho, gamma, obj, True, False, sol=sol, sol_only=True)
+                if n >= 1:
+                    if kind:
+                        sv.stop_test(kind, tol, n, 2, ring[n - 1])
+                    else:
+                        sv.loss_record(ring[n - 1])
             torch.cuda.synchronize(dev)
         ret = [sol.to(b_rows.device)]
         if kwargs.get("return_state"):
             ret.append(tuple(v.to(b_rows.device) for v in st))
         if kwargs.get("return_losses"):
-            ret.append(combine_loss_records(ring[:n], float(H) * float(W), kwargs.get("group")).cpu())
+            ret.append(_finish_records(sv, ring, n, kind, H, W, kwargs.get("group"))[0])
         return ret[0] if len(ret) == 1 else tuple(ret)
     finally:
         sv.close()
 
 
-def _dr_slab(solver: int, n: int, sv: SlabSolver, st, bd, t, rho, gamma, obj, ring):
+def _dr_slab(solver: int, n: int, sv: SlabSolver, st, bd, t, rho, gamma, obj, ring, kind=0, tol=0.0, every=0, first_it=1):
     sv.rows(solver, st, bd, t, rho, gamma, obj, False, True)
     for c in range(1, n + 1):
         sv.column_stage()
         sv.rows(solver, st, bd, t, rho, gamma, obj, True, c < n)
-        sv.loss_record(ring[c - 1])
+        if kind:
+            sv.stop_test(kind, tol, c, first_it, ring[c - 1])
+            if c % every == 0 and sv.stopped_at() >= 0:
+                break
+        else:
+            sv.loss_record(ring[c - 1])
 
 
 def primal_dr_splitting_slab(problem: str, kernel, b_rows: torch.Tensor, image_shape: Tuple[int, int], niters: int = 500, gamma: float = 0.049,
@@ -305,14 +373,15 @@ def primal_dr_splitting_slab(problem: str, kernel, b_rows: torch.Tensor, image_s
         ring = torch.zeros((max(n, 1), 8), dtype=torch.float64, device=dev)
         with torch.cuda.device(dev):
             sv.plan.sync_stream()
+            kind, tol, every = _stop_args(kwargs)
             if n > 0:
-                _dr_slab(SOLVER_PDR, n, sv, (z1, z2), bd, t, rho, gamma, 0 if problem == "l1" else 1, ring)
+                _dr_slab(SOLVER_PDR, n, sv, (z1, z2), bd, t, rho, gamma, 0 if problem == "l1" else 1, ring, kind, tol, every, 3)   # j > 1 (pdr:143)
             torch.cuda.synchronize(dev)
         ret = [prox_box(z1, 1).to(b_rows.device)]                                                     # pdr:184
         if kwargs.get("return_state"):
             ret.append((z1.to(b_rows.device), z2.to(b_rows.device)))
         if kwargs.get("return_losses"):
-            ret.append(combine_loss_records(ring[:n], float(H) * float(W), kwargs.get("group")).cpu())
+            ret.append(_finish_records(sv, ring, n, kind, H, W, kwargs.get("group"))[0])
         return ret[0] if len(ret) == 1 else tuple(ret)
     finally:
         sv.close()
@@ -339,14 +408,15 @@ def primal_dual_dr_splitting_slab(b_rows: torch.Tensor, kernel, image_shape: Tup
         ring = torch.zeros((max(n, 1), 8), dtype=torch.float64, device=dev)
         with torch.cuda.device(dev):
             sv.plan.sync_stream()
+            kind, tol, every = _stop_args(kwargs)
             if n > 0:
-                _dr_slab(SOLVER_PDDR, n, sv, (p, q), bd, t, rho, gamma, 0, ring)
+                _dr_slab(SOLVER_PDDR, n, sv, (p, q), bd, t, rho, gamma, 0, ring, kind, tol, every, 2)   # k > 1 (pddr:103)
             torch.cuda.synchronize(dev)
         ret = [prox_box(p, 1).to(b_rows.device)]                                                      # pddr:136
         if kwargs.get("return_state"):
             ret.append((p.to(b_rows.device), q.to(b_rows.device)))
         if kwargs.get("return_losses"):
-            ret.append(combine_loss_records(ring[:n], float(H) * float(W), kwargs.get("group")).cpu())
+            ret.append(_finish_records(sv, ring, n, kind, H, W, kwargs.get("group"))[0])
         return ret[0] if len(ret) == 1 else tuple(ret)
     finally:
         sv.close()

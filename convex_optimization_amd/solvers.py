@@ -9,8 +9,13 @@ Keyword extensions common to all four (all optional, carried by **kwargs as in t
   return_losses also return the per-iteration loss list
   eig_arrays    {"K","D","M"}: externally supplied eigenvalue arrays (fp64 parity)
   tune          column tiling knobs, see DeblurDenoiseOperators
-Images may carry a leading batch dimension (B, H, W): every image is solved independently, exactly
-as B calls of the reference would, inside one launch sequence.
+Images may carry a leading batch dimension (B, H, W) or (B, C, H, W): every plane is solved independently,
+exactly as B (B*C) calls of the reference would, inside one launch sequence; the result has the same leading
+shape, `return_losses` then gives one list per plane (a plane that stopped early has a shorter list), and the
+progress log lines describe plane 0.
+Loss functions: l1_loss, l2_loss, mse, psnr and ssim of this package are evaluated on the device inside the fused
+loop (no host round trip per iteration, early stop included); any other callable, and save_loss=True, take the
+per-iteration host loop the reference has.
 """
 from __future__ import annotations
 
@@ -29,17 +34,68 @@ from .plan import _ptr, compute_device, real_dtype, stage
 from .utils.logging_utils import log_execution_time, logger, save_loss_data
 
 _KIND_INDEX = {L.LOSS_L1: 0, L.LOSS_L2: 1, L.LOSS_MSE: 2, L.LOSS_PSNR: 3}
+_OWN_LOSSES = (l1_loss, l2_loss, mse, psnr, ssim)
 
 
 def _as_batch(b: torch.Tensor):
-    """(H,W) -> (1,H,W) view info.  Returns (tensor3d, had_batch)."""
+    """(H,W) -> (1,H,W); (B,H,W) as is; (B,C,H,W) -> (B*C,H,W): every plane is an independent image for the
+    reference (multiplying_matrix.py:31).  Returns (tensor3d, had_batch, lead) with lead = (B, C) for 4-D input."""
     if isinstance(b, np.ndarray):
         b = torch.from_numpy(b)
     if b.dim() == 2:
-        return b.unsqueeze(0), False
+        return b.unsqueeze(0), False, None
     if b.dim() == 3:
-        return b, True
-    raise ValueError(f"expected an image of shape (H, W) or (B, H, W), got {tuple(b.shape)}")
+        return b, True, None
+    if b.dim() == 4:
+        return b.reshape(b.shape[0] * b.shape[1], b.shape[2], b.shape[3]), True, (b.shape[0], b.shape[1])
+    raise ValueError(f"expected an image of shape (H, W), (B, H, W) or (B, C, H, W), got {tuple(b.shape)}")
+
+
+def _shape_out(t: torch.Tensor, had_batch: bool, lead):
+    """(B', H, W) result -> the caller's leading shape."""
+    if lead is not None:
+        return t.reshape(*lead, t.shape[-2], t.shape[-1])
+    return t if had_batch else t[0]
+
+
+def _eval_loss(fn, a: torch.Tensor, b: torch.Tensor, src):
+    """loss_function(iterate, b) on the host path.  The package's own losses run on the device tensors (only the scalar
+    comes back); any other callable gets tensors on the device its inputs came from, as the reference would pass them."""
+    if any(fn is f for f in _OWN_LOSSES):
+        v = fn(a, b)
+    else:
+        v = fn(a.to(src), b.to(src))
+    return v.item() if isinstance(v, torch.Tensor) and v.numel() == 1 else v
+
+
+def _loss_lists(vals: torch.Tensor, done, lo: int, had_batch: bool):
+    """vals: [iters][batch] on the host; image i's list covers ring slots lo .. done[i] - 1 (an image that stopped early
+    has no later entries).  One list for a single image, a list per image for a batch."""
+    per = [[float(v) for v in vals[lo:int(done[i]), i]] for i in range(vals.shape[1])]
+    return per if had_batch else per[0]
+
+
+class _SsimRing:
+    """The device record of the in-loop ssim (ddn_plan_set_ssim) for one fused run; switched off again on exit."""
+
+    def __init__(self, plan, kind, n, B, dev):
+        self.plan, self.on = plan, kind == L.LOSS_SSIM
+        self.ring = torch.full((max(n, 1), B, 2), float("nan"), dtype=torch.float64, device=dev) if self.on else None
+
+    def __enter__(self):
+        if self.on:
+            self.plan.set_ssim(self.ring)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.plan.set_ssim(None)
+        return False
+
+    def values(self, ring, kind, pair=0):
+        if self.on:
+            return self.ring[:, :, pair].cpu()
+        return _ring_values(ring, kind, pair)
 
 
 def _loss_kind(loss_function) -> int:
@@ -57,12 +113,6 @@ def _ring_values(ring: torch.Tensor, kind: int, pair: int = 0):
     return r
 
 
-def _metrics_lists(ring, pair, lo):
-    """psnr/mse/l1/l2 lists (image 0) from the device ring for iterations index >= lo."""
-    r = ring[lo:, 0, 4 * pair:4 * pair + 4].cpu().tolist()
-    return {"l1_loss": [v[0] for v in r], "l2_loss": [v[1] for v in r], "mse": [v[2] for v in r], "psnr": [v[3] for v in r]}
-
-
 # =============================================================================== Chambolle-Pock
 @log_execution_time(logger)
 def chambolle_pock(b: torch.Tensor, kernel: torch.Tensor, objective_function: str = "l1", t: float = 0.4, s: float = 0.7,
@@ -72,7 +122,7 @@ def chambolle_pock(b: torch.Tensor, kernel: torch.Tensor, objective_function: st
     if objective_function not in ("l1", "l2"):
         raise ValueError("Invalid objective function. Choose 'l1' or 'l2'.")
     start_time = time.time()
-    b3, _ = _as_batch(b)
+    b3, _, lead = _as_batch(b)
     src = b3.device
     dt = real_dtype(kwargs.get("dtype", b3.dtype))
     dev = compute_device(kwargs.get("device", src))
@@ -100,22 +150,22 @@ def chambolle_pock(b: torch.Tensor, kernel: torch.Tensor, objective_function: st
             ops.plan.sync_stream()
             if kind and not save_loss:
                 ring = torch.zeros((max(n, 1), B, 8), dtype=torch.float64, device=dev)
-                L.check(L.lib().ddn_cp_run(ops.plan._h, _ptr(x), _ptr(z), _ptr(y), _ptr(bd), float(t), float(s), float(gamma),
-                                           L.OBJ[objective_function], n, _ptr(ring)))
-                vals = _ring_values(ring, kind)
-                losses = [float(v) for v in vals[1:n, 0]]                                            # loss for k > 1 (cp:94)
+                with _SsimRing(ops.plan, kind, n, B, dev) as sr:
+                    L.check(L.lib().ddn_cp_run(ops.plan._h, _ptr(x), _ptr(z), _ptr(y), _ptr(bd), float(t), float(s), float(gamma),
+                                               L.OBJ[objective_function], n, _ptr(ring)))
+                    vals = sr.values(ring, kind)
+                losses = _loss_lists(vals, [n] * B, 1, B > 1)                                        # loss for k > 1 (cp:94)
+                first = losses[0] if B > 1 else losses
                 for k in range(2, n + 1):
                     if k % 50 == 0 or k == max_iter - 1:
-                        logger.info(f"Iteration {k} completed. {_loss_name(loss_function)} : {losses[k - 2]}")
+                        logger.info(f"Iteration {k} completed. {_loss_name(loss_function)} : {first[k - 2]}")
             else:
                 lists = {m: [] for m in ("psnr", "ssim", "mse", "l1_loss", "l2_loss")}
                 for k in range(1, n + 1):
                     L.check(L.lib().ddn_cp_run(ops.plan._h, _ptr(x), _ptr(z), _ptr(y), _ptr(bd), float(t), float(s), float(gamma),
                                                L.OBJ[objective_function], 1, C.c_void_p(0)))
                     if k > 1:
-                        xv, bv = (x if B > 1 else x[0:1]).to(src), bd.to(src)
-                        lv = loss_function(xv, bv) if loss_function is not None else 0.0
-                        lv = lv.item() if isinstance(lv, torch.Tensor) and lv.numel() == 1 else lv
+                        lv = _eval_loss(loss_function, x if B > 1 else x[0:1], bd, src) if loss_function is not None else 0.0
                         losses.append(lv)
                         if save_loss:
                             for nm, fn in (("psnr", psnr), ("ssim", ssim), ("mse", mse), ("l1_loss", l1_loss), ("l2_loss", l2_loss)):
@@ -130,9 +180,9 @@ def chambolle_pock(b: torch.Tensor, kernel: torch.Tensor, objective_function: st
                       "loss_function": _loss_name(loss_function)}
             params.update(extra)
             save_loss_data(losses, "chambolle_pock", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
-        out = x.to(src)
-        if b.dim() == 2:
-            out = out                                                                                # reference broadcasts (H,W) b to (1,H,W) at cp:83
+        out = x.to(src)                                                                             # the reference broadcasts (H,W) b to (1,H,W) at cp:83
+        if lead is not None:
+            out = _shape_out(out, True, lead)
         ret = [out]
         if kwargs.get("return_state"):
             ret.append((x.to(src), z.to(src), y.to(src)))
@@ -154,7 +204,7 @@ def admm_solver(b: torch.Tensor, objective_function: str = "l1", t: float = 18, 
     if objective_function not in ("l1", "l2"):
         raise ValueError("Invalid objective function. Choose 'l1' or 'l2'.")
     start_time = time.time()
-    b3, had_batch = _as_batch(b)
+    b3, had_batch, lead = _as_batch(b)
     src = b3.device
     dt = real_dtype(kwargs.get("dtype", b3.dtype))
     dev = compute_device(kwargs.get("device", src))
@@ -188,15 +238,18 @@ def admm_solver(b: torch.Tensor, objective_function: str = "l1", t: float = 18, 
             if (kind or loss_function is None) and not save_loss:
                 ring = torch.zeros((max(n, 1), B, 8), dtype=torch.float64, device=dev)
                 done = torch.zeros((B,), dtype=torch.int32, device=dev)
-                L.check(L.lib().ddn_admm_run(ops.plan._h, _ptr(u), _ptr(w), _ptr(y), _ptr(z), _ptr(bd), float(t), float(rho), float(gamma), obj, n,
-                                             kind, float(tol), 2, _ptr(ring), _ptr(done), _ptr(sol)))
+                with _SsimRing(ops.plan, kind, n, B, dev) as sr:
+                    L.check(L.lib().ddn_admm_run(ops.plan._h, _ptr(u), _ptr(w), _ptr(y), _ptr(z), _ptr(bd), float(t), float(rho), float(gamma), obj, n,
+                                                 kind, float(tol), 2, _ptr(ring), _ptr(done), _ptr(sol)))
+                    if kind:
+                        vals = sr.values(ring, kind)
                 if kind:
-                    nd = int(done.max().item())
-                    vals = _ring_values(ring, kind)
-                    losses = [float(v) for v in vals[1:nd, 0]]                                       # i > 1 (admm:118)
-                    for i in range(2, nd + 1):
+                    dn = done.cpu().tolist()
+                    losses = _loss_lists(vals, dn, 1, had_batch)                                     # i > 1 (admm:118)
+                    first = losses[0] if had_batch else losses
+                    for i in range(2, dn[0] + 1):
                         if i % 50 == 0 or i == niters - 1:
-                            logger.info(f"Iteration {i} completed. {_loss_name(loss_function)} : {losses[i - 2]}")
+                            logger.info(f"Iteration {i} completed. {_loss_name(loss_function)} : {first[i - 2]}")
             else:
                 lists = {m: [] for m in ("psnr", "ssim", "mse", "l1_loss", "l2_loss")}
                 if n == 0:
@@ -206,9 +259,7 @@ def admm_solver(b: torch.Tensor, objective_function: str = "l1", t: float = 18, 
                     L.check(L.lib().ddn_admm_run(ops.plan._h, _ptr(u), _ptr(w), _ptr(y), _ptr(z), _ptr(bd), float(t), float(rho), float(gamma), obj, 1,
                                                  0, 0.0, 2, C.c_void_p(0), C.c_void_p(0), _ptr(sol)))
                     if i > 1:
-                        sv, bv = (sol if had_batch else sol[0]).to(src), (bd if had_batch else bd[0]).to(src)
-                        lv = loss_function(sv, bv)
-                        lv = lv.item() if isinstance(lv, torch.Tensor) and lv.numel() == 1 else lv
+                        lv = _eval_loss(loss_function, sol if had_batch else sol[0], bd if had_batch else bd[0], src)
                         losses.append(lv)
                         if save_loss:
                             for nm, fn in (("psnr", psnr), ("ssim", ssim), ("mse", mse), ("l1_loss", l1_loss), ("l2_loss", l2_loss)):
@@ -226,7 +277,7 @@ def admm_solver(b: torch.Tensor, objective_function: str = "l1", t: float = 18, 
                       "loss_function": _loss_name(loss_function)}
             params.update(extra)
             save_loss_data(losses, "admm", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
-        out = (sol if had_batch else sol[0]).to(src)
+        out = _shape_out(sol, had_batch, lead).to(src)
         ret = [out]
         if kwargs.get("return_state"):
             ret.append((u.to(src), w.to(src), y.to(src), z.to(src)))
@@ -246,7 +297,7 @@ def primal_dr_splitting(problem: str, kernel: torch.Tensor, b: torch.Tensor, ima
     selects the l1 data term, anything else the squared-l2 one (pdr:101-110).  Runs up to niters
     iterations; stops when loss_function(z1, z1prev) < tol for j > 1 (pdr:143-161); returns clip(z1)."""
     start_time = time.time()
-    b3, had_batch = _as_batch(b)
+    b3, had_batch, lead = _as_batch(b)
     src = b3.device
     dt = real_dtype(kwargs.get("dtype", b3.dtype))
     dev = compute_device(kwargs.get("device", src))
@@ -272,16 +323,18 @@ def primal_dr_splitting(problem: str, kernel: torch.Tensor, b: torch.Tensor, ima
             if (kind or loss_function is None) and not save_loss:
                 ring = torch.zeros((max(n, 1), B, 8), dtype=torch.float64, device=dev)
                 done = torch.zeros((B,), dtype=torch.int32, device=dev)
-                L.check(L.lib().ddn_pdr_run(ops.plan._h, _ptr(z1), _ptr(z2), _ptr(bd), float(t), float(rho), float(gamma), obj, n,
-                                            kind, float(tol), 3, _ptr(ring), _ptr(done)))
+                with _SsimRing(ops.plan, kind, n, B, dev) as sr:
+                    L.check(L.lib().ddn_pdr_run(ops.plan._h, _ptr(z1), _ptr(z2), _ptr(bd), float(t), float(rho), float(gamma), obj, n,
+                                                kind, float(tol), 3, _ptr(ring), _ptr(done)))
+                    if kind:
+                        vals = sr.values(ring, kind)
+                        vb = sr.values(ring, kind, pair=1)
                 if kind:
-                    nd = int(done.max().item())
-                    vals = _ring_values(ring, kind)
-                    losses = [float(v) for v in vals[2:nd, 0]]                                       # j > 1 (pdr:143)
-                    vb = _ring_values(ring, kind, pair=1)
-                    for j in range(0, nd, 50):
+                    dn = done.cpu().tolist()
+                    losses = _loss_lists(vals, dn, 2, had_batch)                                     # j > 1 (pdr:143)
+                    for j in range(0, dn[0], 50):
                         logger.info(f"Iteration {j} completed. {_loss_name(loss_function)} loss : {float(vb[j, 0])}")
-                    if nd == n:
+                    if max(dn) == n:
                         logger.info(f"Warning: maxiter reached ({niters}), primal_dr did not converge")
             else:
                 lists = {m: [] for m in ("psnr", "ssim", "mse", "l1_loss", "l2_loss")}
@@ -292,12 +345,10 @@ def primal_dr_splitting(problem: str, kernel: torch.Tensor, b: torch.Tensor, ima
                                                 0, 0.0, 3, C.c_void_p(0), C.c_void_p(0)))
                     zv = (z1 if had_batch else z1[0])
                     if j % 50 == 0:
-                        lv = loss_function(zv.to(src), (bd if had_batch else bd[0]).to(src))
-                        lv = lv.item() if isinstance(lv, torch.Tensor) and lv.numel() == 1 else lv
+                        lv = _eval_loss(loss_function, zv, bd if had_batch else bd[0], src)
                         logger.info(f"Iteration {j} completed. {_loss_name(loss_function)} loss : {lv}")
                     if j > 1:
-                        lv = loss_function(zv.to(src), (z1prev if had_batch else z1prev[0]).to(src))
-                        lv = lv.item() if isinstance(lv, torch.Tensor) and lv.numel() == 1 else lv
+                        lv = _eval_loss(loss_function, zv, z1prev if had_batch else z1prev[0], src)
                         losses.append(lv)
                         if save_loss:
                             for nm, fn in (("psnr", psnr), ("ssim", ssim), ("mse", mse), ("l1_loss", l1_loss), ("l2_loss", l2_loss)):
@@ -315,7 +366,7 @@ def primal_dr_splitting(problem: str, kernel: torch.Tensor, b: torch.Tensor, ima
             params.update(extra)
             save_loss_data(losses, "primal_dr_splitting", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
         solution = prox_box(z1, t)                                                                  # pdr:182-187
-        out = (solution if had_batch else solution[0]).to(src)
+        out = _shape_out(solution, had_batch, lead).to(src)
         ret = [out]
         if kwargs.get("return_state"):
             ret.append((z1.to(src), z2.to(src)))
@@ -335,9 +386,9 @@ def primal_dual_dr_splitting(b: torch.Tensor, kernel: torch.Tensor, niters: int 
     (pddr:103-121); returns clip(p)."""
     start_time = time.time()
     if isinstance(b, torch.Tensor) and b.dim() == 3 and b.shape[0] == 1:
-        b3, had_batch = b, False                                                                    # pddr:52-56: (1,H,W) is squeezed
+        b3, had_batch, lead = b, False, None                                                        # pddr:52-56: (1,H,W) is squeezed
     else:
-        b3, had_batch = _as_batch(b)
+        b3, had_batch, lead = _as_batch(b)
     src = b3.device
     dt = real_dtype(kwargs.get("dtype", b3.dtype))
     dev = compute_device(kwargs.get("device", src))
@@ -364,15 +415,18 @@ def primal_dual_dr_splitting(b: torch.Tensor, kernel: torch.Tensor, niters: int 
             if (kind or loss_function is None) and not save_loss:
                 ring = torch.zeros((max(n, 1), B, 8), dtype=torch.float64, device=dev)
                 done = torch.zeros((B,), dtype=torch.int32, device=dev)
-                L.check(L.lib().ddn_pddr_run(ops.plan._h, _ptr(p), _ptr(q), _ptr(bd), float(t), float(rho), float(gamma), n,
-                                             kind, float(tol), 2, _ptr(ring), _ptr(done)))
+                with _SsimRing(ops.plan, kind, n, B, dev) as sr:
+                    L.check(L.lib().ddn_pddr_run(ops.plan._h, _ptr(p), _ptr(q), _ptr(bd), float(t), float(rho), float(gamma), n,
+                                                 kind, float(tol), 2, _ptr(ring), _ptr(done)))
+                    if kind:
+                        vals = sr.values(ring, kind)
                 if kind:
-                    nd = int(done.max().item())
-                    vals = _ring_values(ring, kind)
-                    losses = [float(v) for v in vals[1:nd, 0]]                                       # k > 1 (pddr:103)
-                    for k in range(2, nd + 1):
+                    dn = done.cpu().tolist()
+                    losses = _loss_lists(vals, dn, 1, had_batch)                                     # k > 1 (pddr:103)
+                    first = losses[0] if had_batch else losses
+                    for k in range(2, dn[0] + 1):
                         if k % 50 == 0:
-                            logger.info(f"Iteration {k} completed. {_loss_name(loss_function)} loss : {losses[k - 2]}")
+                            logger.info(f"Iteration {k} completed. {_loss_name(loss_function)} loss : {first[k - 2]}")
             else:
                 lists = {m: [] for m in ("psnr", "ssim", "mse", "l1_loss", "l2_loss")}
                 for k in range(1, n + 1):
@@ -380,8 +434,7 @@ def primal_dual_dr_splitting(b: torch.Tensor, kernel: torch.Tensor, niters: int 
                                                  0, 0.0, 2, C.c_void_p(0), C.c_void_p(0)))
                     if k > 1:
                         sol = prox_box(p, 1)
-                        lv = loss_function((sol if B > 1 else sol[0]).to(src), bd.to(src))
-                        lv = lv.item() if isinstance(lv, torch.Tensor) and lv.numel() == 1 else lv
+                        lv = _eval_loss(loss_function, sol if B > 1 else sol[0], bd, src)
                         losses.append(lv)
                         if save_loss:
                             for nm, fn in (("psnr", psnr), ("ssim", ssim), ("mse", mse), ("l1_loss", l1_loss), ("l2_loss", l2_loss)):
@@ -399,7 +452,7 @@ def primal_dual_dr_splitting(b: torch.Tensor, kernel: torch.Tensor, niters: int 
             params.update(extra)
             save_loss_data(losses, "primal_dual_dr_splitting", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
         x_sol = prox_box(p, 1)                                                                      # pddr:123
-        out = (x_sol if had_batch else x_sol[0]).to(src)
+        out = _shape_out(x_sol, had_batch, lead).to(src)
         ret = [out]
         if kwargs.get("return_state"):
             ret.append((p.to(src), q.to(src)))

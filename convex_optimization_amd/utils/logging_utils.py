@@ -57,6 +57,10 @@ def save_loss_data(loss_list: List[float], algorithm_name: str, loss_function_na
         else:
             df[key] = val
     path = out_dir / f"{algorithm_name}_{loss_function_name}_{int(start_time)}.csv"
-    df.to_csv(path, index=False)
-    logger.info(f"Saved loss data to {path}")
+    if path.exists():
+        df.to_csv(path, mode="a", header=False, index=False)     # the reference appends to an existing file (lu:128-131)
+        logger.info(f"Loss data appended to existing file {path}")
+    else:
+        df.to_csv(path, index=False)
+        logger.info(f"Loss data saved to new file {path}")
     return str(path)

@@ -51,6 +51,7 @@ extern "C" {
 #define DDN_LOSS_L2 2
 #define DDN_LOSS_MSE 3
 #define DDN_LOSS_PSNR 4
+#define DDN_LOSS_SSIM 5   /* core/loss.py:39-110; needs ddn_plan_set_ssim */
 
 /* spectral operators for ddn_apply (op_math/python_code/multiplying_matrix.py:74-112) */
 #define DDN_OP_K 0          /* apply_K           mm:74-76   */
@@ -105,7 +106,8 @@ int ddn_plan_set_resolvent(ddn_plan* p, double cK, double cD, const void* M_dev,
 int ddn_plan_get_eigK(ddn_plan* p, void* out_dev);
 
 /* y = real(ifft2(e * fft2(x))) for a built-in operator (apply_periodic_conv_2d.py:28
- * via mm:74-112).  x, y: [batch][H][W]; may alias. */
+ * via mm:74-112).  x, y: [batch][H][W]; may alias, except for DDN_OP_D / DDN_OP_DT without injected
+ * eigen arrays (a two-tap stencil there, which rejects x == y with DDN_E_ARG). */
 int ddn_apply(ddn_plan* p, int op, const void* x_dev, void* y_dev);
 
 /* y = real(ifft2(mult * fft2(x))) with an arbitrary multiplier (device, H x W complex,
@@ -150,6 +152,17 @@ int ddn_ssim(int dtype, const void* x_dev, const void* y_dev, int H, int W, int 
  * zero padding kernel_size / 2>.  kernel_size must be odd: for even sizes the reference's padded
  * correlation has kernel_size + 1 rows and its product with w raises. */
 int ddn_apply_x_trans(int dtype, const void* w_dev, const void* x_dev, int kernel_size, void* out_dev, void* stream);
+
+/* ssim (core/loss.py:39-110) as the loss evaluated inside the solver loops: the default loss_function of
+ * primal_dr_splitting (primal_dr/algorithm.py:25) and of deblur_image / blur_and_deblur_image (blur_deblur.py:87,153).
+ * g11_host: the 11 window factors as for ddn_ssim; ssim_ring_dev: device doubles [n_iters][batch][2], caller-owned, which
+ * the following *_run calls fill (the caller pre-fills it, e.g. with NaN): entry 0 of iteration i's slot = ssim of the
+ * solver's primary pair after iteration i (cp: (x, b); admm: (sol, b); pdr: (z1, z1prev); pddr: (clip(p), b)),
+ * entry 1 (pdr only, every 50th iteration from the first: the reference's logging cadence, pdr:137-141) = ssim(z1, b).
+ * With tol_kind = DDN_LOSS_SSIM the stop test `loss < tol` is made on entry 0, on the device, as for the other kinds;
+ * ddn_cp_run (which has no stop test) records whenever a ring is set.  ssim_ring_dev = NULL switches it off.
+ * Cost per iteration: one pass over the two images (plus, for pdr, one copy of z1). */
+int ddn_plan_set_ssim(ddn_plan* p, const float* g11_host, double max_val, double* ssim_ring_dev);
 
 /* ---- solver loops -------------------------------------------------------------
  * Each *_run advances the iterate arrays in place by up to n_iters iterations of the
@@ -223,9 +236,26 @@ int ddn_pddr_run(ddn_plan* p, void* p_dev, void* q_dev, const void* b_dev,
  *                   the LOCAL rows seen by the last consuming ddn_slab_rows launch; l1 and l2^2
  *                   add up over ranks (mse and psnr are per-slab figures over the full pixel count).
  * The exchange between the two buffers is an all-to-all owned by the caller (RCCL through
- * torch.distributed in this package).  No early stop inside these calls.  Injected eigen arrays
+ * torch.distributed in this package).  Early stop: ddn_slab_begin / ddn_slab_stop_test below.  Injected eigen arrays
  * (ddn_plan_set_eig, ddn_plan_set_resolvent with M_dev: the fp64 parity route) are honoured. */
 int ddn_slab_layout(ddn_plan* p, int* tile_cols, int* n_tiles);
+/* Early stop of a slab solve (the reference's `break`: admm:152-154, pdr:159-161, pddr:119-121) without a host round
+ * trip.  The stop flag lives in the plan; every ddn_slab_rows / ddn_slab_rows_cp launch skips its rows once it is set,
+ * so the iterates stay as they were when the test fired (ADMM: pass sol_out_dev in every consuming launch, as
+ * ddn_admm_run does, so that the look-ahead solution of the stopping iteration is what remains in it).
+ *   ddn_slab_begin       clears the flag: call once at the start of a solve.
+ *   ddn_slab_loss_sums   sums4_dev[0..3] = sum |d|, sum d^2 of the primary pair, then of the secondary pair, over the
+ *                        LOCAL rows of the last consuming launch: the caller all-reduces (SUM) these four doubles.
+ *   ddn_slab_stop_test   from the all-reduced sums: record8_dev (may be NULL) = l1, l2, mse, psnr of both pairs for the
+ *                        whole image, and the flag <- iter when iter >= first_iter and the value of `kind`
+ *                        (DDN_LOSS_L1..PSNR, primary pair) is below tol.  Every rank makes the same decision from the
+ *                        same sums.  kind = DDN_LOSS_NONE only records.
+ *   ddn_slab_iters_done  done_dev[0] (int32, device) = -1 while running, else the iteration at which the solve froze;
+ *                        lets the host leave its launch loop (poll it every few iterations, not every one). */
+int ddn_slab_begin(ddn_plan* p);
+int ddn_slab_loss_sums(ddn_plan* p, int rows, double* sums4_dev);
+int ddn_slab_stop_test(ddn_plan* p, const double* sums4_dev, int kind, double tol, int iter, int first_iter, double* record8_dev);
+int ddn_slab_iters_done(ddn_plan* p, int* done_dev);
 int ddn_slab_rows(ddn_plan* p, int solver, int rows, void* spec_rows_dev, void* s0_dev, void* s1_dev, void* s2_dev, void* s3_dev,
                   const void* b_dev, double t, double rho, double gamma, int objective, int consume, int produce,
                   void* sol_out_dev, int sol_only);

@@ -68,6 +68,8 @@ def test_no_cpu_fallback():
         pkg.core.prox_l1(b, 0.1)
     with pytest.raises(DdnError):
         pkg.DeblurDenoiseOperators(k, b, 1.0)
+    with pytest.raises(DdnError):
+        pkg.core.ssim(b, b)
 
 
 def test_host_side_kernels_match_golden(golden_dir):
@@ -84,6 +86,7 @@ def test_host_side_kernels_match_golden(golden_dir):
     assert np.array_equal(create_motion_blur_kernel(8, 120).numpy(), g["motion8_120"])
 
 
+@pytest.mark.gpu
 def test_ssim_matches_golden(golden_dir):
     import numpy as np
     from convex_optimization_amd.core.loss import ssim

@@ -1,0 +1,96 @@
+"""CPU-side check of the built gfx950 code objects inside libddn.so: the register-resident kernels (one wavefront
+holds a whole 4096-point sequence in registers) are written so that nothing of that sequence is spilled.  The
+compiler's register allocation is steered by source-level devices (opaque offsets, pins, a raised unroll threshold),
+which a toolchain update could silently undo; this test reads the kernels' metadata notes and fails when a hot
+kernel's private segment (scratch memory per lane) grows beyond what is recorded here."""
+import os
+import struct
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "convex_optimization_amd", "libddn.so")
+
+msgpack = pytest.importorskip("msgpack")
+
+
+def _kernels_of(path):
+    """name -> metadata dict of every AMDGPU kernel in the ELF code objects embedded in `path`."""
+    data = open(path, "rb").read()
+    out = {}
+    pos = 0
+    while True:
+        off = data.find(b"\x7fELF", pos)
+        if off < 0:
+            break
+        pos = off + 4
+        if data[off + 4] != 2 or len(data) < off + 64:
+            continue
+        e_machine = struct.unpack_from("<H", data, off + 18)[0]
+        if e_machine != 224:        # EM_AMDGPU
+            continue
+        e_shoff = struct.unpack_from("<Q", data, off + 0x28)[0]
+        e_shentsize, e_shnum = struct.unpack_from("<HH", data, off + 0x3A)
+        for i in range(e_shnum):
+            sh = off + e_shoff + i * e_shentsize
+            if sh + 64 > len(data):
+                break
+            sh_type = struct.unpack_from("<I", data, sh + 4)[0]
+            if sh_type != 7:        # SHT_NOTE
+                continue
+            sh_offset, sh_size = struct.unpack_from("<QQ", data, sh + 0x18)
+            p, end = off + sh_offset, off + sh_offset + sh_size
+            while p + 12 <= end:
+                namesz, descsz, ntype = struct.unpack_from("<III", data, p)
+                p += 12
+                name = data[p:p + namesz].rstrip(b"\0")
+                p += (namesz + 3) & ~3
+                desc = data[p:p + descsz]
+                p += (descsz + 3) & ~3
+                if name == b"AMDGPU" and ntype == 32:       # NT_AMDGPU_METADATA (msgpack)
+                    md = msgpack.unpackb(desc, raw=False, strict_map_key=False)
+                    for k in md.get("amdhsa.kernels", []):
+                        out[k[".name"]] = k
+    return out
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    assert os.path.exists(LIB), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    ks = _kernels_of(LIB)
+    assert len(ks) > 50, f"found only {len(ks)} kernels in the embedded code objects"
+    return ks
+
+
+def _family(kernels, token):
+    fam = {n: k for n, k in kernels.items() if token in n}
+    assert fam, f"no kernel named *{token}* in libddn.so"
+    return fam
+
+
+@pytest.mark.parametrize("token", ["k_wave_rowI", "k_wave_cpI", "k_wave_rowNI", "k_wave_cpNI"])
+def test_register_resident_kernels_do_not_spill(kernels, token):
+    """Row kernels (W = 4096 and 512-2048) and the Chambolle-Pock row kernels: zero scratch."""
+    bad = {n: (k[".private_segment_fixed_size"], k.get(".vgpr_spill_count")) for n, k in _family(kernels, token).items()
+           if k[".private_segment_fixed_size"] != 0}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("token", ["k_wave_colILi", "k_wave_colNILi"])
+def test_wave_column_kernel_scratch_is_bounded(kernels, token):
+    """The column kernels (H = 4096; H = 512-2048): the multiplier-mode variants use no scratch; the resolvent-mode
+    variants park at most two dozen registers around the pointwise stage (stored once, reloaded once per workgroup: not
+    in any inner loop).  A larger private segment means the transform's registers are being spilled."""
+    for n, k in _family(kernels, token).items():
+        res2 = (token + "0E") in n              # MODE = COL_RES2
+        limit = 96 if res2 else 0
+        assert k[".private_segment_fixed_size"] <= limit, (n, k[".private_segment_fixed_size"], k.get(".vgpr_spill_count"))
+        assert k[".vgpr_count"] <= 256, (n, k[".vgpr_count"])
+
+
+def test_two_waves_per_simd(kernels):
+    """Every register-resident kernel must fit two wavefronts per SIMD (256 registers each): one more register and the
+    CU holds four rows or columns instead of eight."""
+    for token in ["k_wave_rowI", "k_wave_cpI", "k_wave_rowNI", "k_wave_cpNI", "k_wave_colILi", "k_wave_colNI"]:
+        for n, k in _family(kernels, token).items():
+            assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 256, (n, k[".vgpr_count"], k.get(".agpr_count"))

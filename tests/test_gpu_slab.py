@@ -224,3 +224,64 @@ def test_two_ranks_vs_reference_iterates(fname, dtname, tol):
         res = dict(out[r])
         bad = {k: v for k, v in res.items() if not v < tol}
         assert not bad, (r, bad)
+
+
+# ------------------------------------------------------------------ early stop on row slabs
+def _stop_worker(rank, world, port, out):
+    import torch.distributed as dist
+    import convex_optimization_amd.slab as S
+    import convex_optimization_amd as pkg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        H = W = 64
+        kern, b, stA, stP, stC = _problem(H, W, "gauss9", torch.float32)
+        rows = H // world
+        sl = slice(rank * rows, (rank + 1) * rows)
+        res = {}
+        # primal DR: loss(z1, z1prev) = mse below 2e-4 after a handful of iterations (pdr:143-161)
+        ol = []
+        xo = O.primal_dr_splitting("l1", kern, b, niters=60, loss_function=O.mse, tol=2e-4, losses=ol)
+        x, rec = S.primal_dr_splitting_slab("l1", kern, b[sl], (H, W), niters=60, loss_function=pkg.core.mse, tol=2e-4, check_every=4, return_losses=True)
+        res["pdr_iters"] = (rec.shape[0], len(ol) + 2)          # the oracle records j > 1: two fewer than the iterations applied
+        res["pdr"] = rel(x.numpy(), xo[sl].numpy())
+        res["pdr_loss"] = float(np.max(np.abs(rec[2:, 2].numpy() - np.asarray(ol)) / np.asarray(ol)))
+        # ADMM: the look-ahead solution of the stopping iteration is returned (admm:118-154)
+        ol = []
+        xo = O.admm_solver(b, "l1", t=18, rho=0.001, gamma=0.5, kernel=kern, niters=40, tol=2.2e-2, loss_function=O.mse, init_state=stA, losses=ol)
+        x, rec = S.admm_solver_slab(b[sl], (H, W), "l1", kernel=kern, niters=40, tol=2.2e-2, loss_function=pkg.core.mse, check_every=3,
+                                    init_state=[v[..., sl, :] for v in stA], return_losses=True)
+        res["admm_iters"] = (rec.shape[0], len(ol) + 1)         # i > 1: one fewer
+        res["admm"] = rel(x.numpy(), xo[sl].numpy())
+        # primal-dual DR: loss(clip(p), b), l2, stops where the oracle does (pddr:103-121)
+        ol = []
+        xo = O.primal_dual_dr_splitting(b, kern, niters=40, init_state=stP, loss_function=O.l2_loss, tol=7.5, losses=ol)
+        x, rec = S.primal_dual_dr_splitting_slab(b[sl], kern, (H, W), niters=40, loss_function=pkg.core.l2_loss, tol=7.5, check_every=5,
+                                                 init_state=[v[..., sl, :] for v in stP], return_losses=True)
+        res["pddr_iters"] = (rec.shape[0], len(ol) + 1)
+        res["pddr"] = rel(x.numpy(), xo[sl].numpy())
+        res["pddr_len"] = len(ol)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_early_stop_matches_oracle():
+    """The reference's `break` on row slabs: the loss sums of both ranks are all-reduced every iteration, the stop test
+    runs on the device on every rank, and both freeze at the oracle's iteration although the host polls the flag only
+    every few iterations."""
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_stop_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        res = dict(out[r])
+        for name in ("pdr", "admm", "pddr"):
+            got, want = res[name + "_iters"]
+            assert got == want, (r, name, got, want)
+            assert res[name] < 1e-5, (r, name, res[name])
+        assert res["pdr_loss"] < 2e-4
+        assert res["pdr_iters"][0] < 40 and res["admm_iters"][0] < 39 and 2 < res["pddr_len"] < 38, res

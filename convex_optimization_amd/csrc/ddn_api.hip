@@ -15,6 +15,7 @@
 #include "../../include/ddn.h"
 #include "ddn_kernels.hpp"
 #include "ddn_launch.hpp"
+#include "ddn_long_args.hpp"
 
 #define DDN_DECL_ROW(T)                                                                                              \
     extern template int row_launch<T, PdrP<T>>(hipStream_t, int, int, size_t, int, const RowCommon<T>&, const PdrP<T>::Args&);   \
@@ -23,6 +24,14 @@
     extern template int cp_launch<T>(hipStream_t, int, int, size_t, int, const RowCommon<T>&, const CpArgs<T>&);
 DDN_DECL_ROW(float)
 DDN_DECL_ROW(double)
+#define DDN_DECL_LONG(T)                                                                                                         \
+    extern template int long_row_launch<T, PdrP<T>>(hipStream_t, int, const LongArgs<T>&, const PdrP<T>::Args&);                 \
+    extern template int long_row_launch<T, PddrP<T>>(hipStream_t, int, const LongArgs<T>&, const PddrP<T>::Args&);               \
+    extern template int long_row_launch<T, AdmmP<T>>(hipStream_t, int, const LongArgs<T>&, const AdmmP<T>::Args&);               \
+    extern template int long_cp_launch<T>(hipStream_t, int, const LongArgs<T>&, const CpArgs<T>&);                                \
+    extern template int long_plain_launch<T>(hipStream_t, int, const LongArgs<T>&, const T*, T*, T);
+DDN_DECL_LONG(float)
+DDN_DECL_LONG(double)
 
 namespace {
 
@@ -167,6 +176,13 @@ struct ddn_plan {
     double* ssim_part = nullptr;   // per-tile partial sums
     double* ssim_val = nullptr;    // [batch]
     void* ssim_prev = nullptr;     // copy of the previous iterate (primal DR compares z1 with z1prev)
+    // rows wider than one workgroup's LDS holds (ddn_long.hpp): W = long_R x long_M
+    int long_R = 0, long_M = 0;
+    FftDesc fl{};              // the length-long_M transform
+    void* twL = nullptr;       // its twiddle table
+    void* edL = nullptr;       // analytic row-spectral D, eD[k] = 1 - w_W^k, k <= W/2
+    void* Ylong = nullptr;     // [3][rows][R/2 + 1][M] complex, sized for Ylong_rows rows
+    size_t Ylong_rows = 0;
     void* nyq_taps = nullptr;  // blur taps transformed along the rows at column W/2 (real, kh entries): see RowCommon::nyq_taps
     int nyq_kh = 0, nyq_ph = 0;
     bool nyq_fir_on = false;   // a Chambolle-Pock loop runs with column W/2 handled by the row kernels
@@ -333,6 +349,17 @@ int plan_alloc(ddn_plan* p) {
         void** dst = side ? &p->wtwH : &p->wtwW;
         HIPCHK(hipMalloc(dst, tab.size() * sizeof(cx<float>)));
         HIPCHK(hipMemcpy(*dst, tab.data(), tab.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
+    }
+    if (p->long_R) {
+        if ((rc = make_table<T>(p->long_M, (cx<T>**)&p->twL))) return rc;
+        std::vector<cx<T>> ed((size_t)p->Wh + 64);
+        for (int k = 0; k < p->Wh; ++k) {
+            const long double ang = -2.0L * 3.14159265358979323846264338327950288L * k / p->W;
+            ed[k].x = (T)(1.0L - cosl(ang));
+            ed[k].y = (T)(-sinl(ang));
+        }
+        HIPCHK(hipMalloc(&p->edL, ed.size() * sizeof(cx<T>)));
+        HIPCHK(hipMemcpy(p->edL, ed.data(), ed.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
     }
     if ((rc = alloc_col_tables<T>(p))) return rc;
     if ((rc = alloc_spec<T>(p))) return rc;
@@ -543,6 +570,11 @@ struct RowCfg {
 template <typename T>
 bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool cp = false) {
     const int W = p->W;
+    if (p->long_R) {
+        // rows wider than 8192 pixels: the three-kernel split transform (ddn_long.hpp); V = -1 marks it
+        rc.V = -1; rc.threads = 256; rc.lds = 0; rc.grid = 1;
+        return true;
+    }
     // A wavefront of the register-resident kernels works through its rows alone (two transforms and the pixel
     // loop in sequence, 35-40 us whatever the image size); with fewer wavefronts than a quarter of the CUs
     // (half for Chambolle-Pock, whose wavefronts carry twice the rows) the workgroup-per-row LDS kernels
@@ -608,17 +640,54 @@ RowCommon<T> row_common(ddn_plan* p, int V, bool consume, bool produce) {
 
 inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
+// ---- long rows -------------------------------------------------------------------------------------------
+template <typename T>
+int long_args(ddn_plan* p, const RowCommon<T>& c, int narr, LongArgs<T>& a) {
+    const size_t rows = (size_t)c.batch * c.H;
+    if (rows > p->Ylong_rows) {
+        if (p->Ylong) {
+            HIPCHK(hipStreamSynchronize(p->stream));
+            (void)hipFree(p->Ylong);
+            p->Ylong = nullptr;
+        }
+        HIPCHK(hipMalloc(&p->Ylong, 3 * rows * (size_t)(p->long_R / 2 + 1) * p->long_M * sizeof(cx<T>)));
+        p->Ylong_rows = rows;
+    }
+    std::memset(&a, 0, sizeof(a));
+    a.c = c;
+    a.Y = (cx<T>*)p->Ylong;
+    a.twM = (const cx<T>*)p->twL;
+    a.ed = p->injected ? (const cx<T>*)p->eDrow : (const cx<T>*)p->edL;
+    a.fm = p->fl;
+    a.R = p->long_R; a.M = p->long_M;
+    a.narr = narr;
+    return DDN_OK;
+}
+
 // fused solver row kernels live in their own translation units (ddn_row_*.hip), one per policy
 // and dtype, so that they compile in parallel; see ddn_launch.hpp.
 template <typename T, class P>
 int launch_solver_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, const typename P::Args& a) {
     TimerScope ts(p, true, c.do_consume && c.do_produce);
+    if (cfg.V == -1) {
+        LongArgs<T> la;
+        int rc = long_args<T>(p, c, 3, la);
+        if (rc) return rc;
+        return long_row_launch<T, P>(p->stream, p->num_cu, la, a);
+    }
     return row_launch<T, P>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.V, c, a);
 }
 
 template <typename T>
 int launch_cp_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, const CpArgs<T>& a) {
     TimerScope ts(p, true, c.do_consume && c.do_produce);
+    if (cfg.V == -1) {
+        if (p->injected) return fail(DDN_E_UNSUPPORTED, "chambolle_pock with injected eigen arrays: rows wider than 8192 pixels are not supported");
+        LongArgs<T> la;
+        int rc = long_args<T>(p, c, 1, la);
+        if (rc) return rc;
+        return long_cp_launch<T>(p->stream, p->num_cu, la, a);
+    }
     return cp_launch<T>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.V, c, a);
 }
 
@@ -666,6 +735,15 @@ int rows_r2c(ddn_plan* p, const T* src, int nplanes) {
     std::memset(&a, 0, sizeof(a));
     a.H = p->H; a.W = p->W; a.batch = nplanes;
     a.fw = p->fw; a.lay = layout_of(p); a.twW = (const cx<T>*)p->twW; a.S = (cx<T>*)p->S0; a.src = src;
+    if (p->long_R) {
+        RowCommon<T> c;
+        std::memset(&c, 0, sizeof(c));
+        c.H = p->H; c.W = p->W; c.batch = nplanes; c.lay = layout_of(p); c.S0 = (cx<T>*)p->S0; c.S1 = (cx<T>*)p->S1; c.do_produce = 1;
+        LongArgs<T> la;
+        int rcl = long_args<T>(p, c, 1, la);
+        if (rcl) return rcl;
+        return long_plain_launch<T>(p->stream, p->num_cu, la, src, (T*)nullptr, (T)1);
+    }
     const size_t lds = row_lds_bytes<T>(p->W, 1);
     if (lds > kLdsMax) return fail(DDN_E_UNSUPPORTED, "row length too large for LDS");
     auto fn = k_rows_r2c<T>;
@@ -684,6 +762,15 @@ int rows_c2r(ddn_plan* p, T* dst, int nplanes, T scale, const T* add) {
     a.H = p->H; a.W = p->W; a.batch = nplanes;
     a.fw = p->fw; a.lay = layout_of(p); a.twW = (const cx<T>*)p->twW; a.S = (cx<T>*)p->S0; a.dst = dst; a.scale = scale;
     (void)add;
+    if (p->long_R) {
+        RowCommon<T> c;
+        std::memset(&c, 0, sizeof(c));
+        c.H = p->H; c.W = p->W; c.batch = nplanes; c.lay = layout_of(p); c.S0 = (cx<T>*)p->S0; c.S1 = (cx<T>*)p->S1; c.do_consume = 1;
+        LongArgs<T> la;
+        int rcl = long_args<T>(p, c, 1, la);
+        if (rcl) return rcl;
+        return long_plain_launch<T>(p->stream, p->num_cu, la, (const T*)nullptr, dst, scale);
+    }
     const size_t lds = row_lds_bytes<T>(p->W, 1);
     auto fn = k_rows_c2r<T>;
     int rc;
@@ -1342,10 +1429,22 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
         return fail(DDN_E_UNSUPPORTED, "plan_create: column transform does not fit LDS");
     }
     if (p->A == 1) p->fb = p->fh;
-    const size_t rl = dtype == DDN_F32 ? row_lds_bytes<float>(W, 4) : row_lds_bytes<double>(W, 4);
-    if (rl > kLdsMax) {
-        delete p;
-        return fail(DDN_E_UNSUPPORTED, "plan_create: row length too large for LDS");
+    const size_t rl = dtype == DDN_F32 ? row_lds_bytes<float>(W, 1) : row_lds_bytes<double>(W, 1);
+    if (rl > kLdsMax || getenv("DDN_FORCE_LONG_ROWS")) {
+        // the row transform is split W = R x M (ddn_long.hpp); DDN_FORCE_LONG_ROWS: the same path on short rows, for tests
+        const int forced = getenv("DDN_FORCE_LONG_ROWS") ? atoi(getenv("DDN_FORCE_LONG_ROWS")) : 0;   // 2, 4, 8, 16: that split; else the smallest
+        for (int R : {2, 4, 8, 16}) {
+            if (forced >= 2 && R != forced) continue;
+            if (W % R == 0 && W / R <= 4096 && W / R >= 2 && factorize(W / R, p->fl)) {
+                p->long_R = R;
+                p->long_M = W / R;
+                break;
+            }
+        }
+        if (!p->long_R) {
+            delete p;
+            return fail(DDN_E_UNSUPPORTED, "plan_create: row length too large (W must be 2, 4, 8 or 16 times a length of at most 4096 with prime factors <= 13)");
+        }
     }
     int rc = dtype == DDN_F32 ? plan_alloc<float>(p) : plan_alloc<double>(p);
     if (rc) {
@@ -1363,7 +1462,7 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
 
 int ddn_plan_destroy(ddn_plan* p) {
     if (!p) return DDN_OK;
-    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->nyqd, p->ssim_part, p->ssim_val, p->ssim_prev, p->nyq_taps, p->eKc, p->ctab, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
+    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->twL, p->edL, p->Ylong, p->nyqd, p->ssim_part, p->ssim_val, p->ssim_prev, p->nyq_taps, p->eKc, p->ctab, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : p->ev_pool) {

@@ -1,0 +1,274 @@
+// Rows longer than one workgroup's LDS holds (W > 8192: the 16384- and 32768-pixel rows of very large images).
+//
+// The length-W row transform is split four-step style, W = R x M with M <= 4096 and R in {2, 4, 8, 16}:
+// pixel n = M j + m, frequency k = R kappa + q,
+//     Z[R kappa + q] = sum_m w_M^(m kappa) [ w_W^(m q) sum_j z[M j + m] w_R^(j q) ].
+// Three kernels replace the fused row kernel of the shorter rows (the reference transforms any row length in
+// one fft2 call: apply_periodic_conv_2d.py:28, multiplying_matrix.py:110-112):
+//   k_long_inv   one workgroup per (row, array, q <= R/2): gathers Z[R kappa + q] of one real array from its
+//                half-spectrum (Hermitian extension for k > W/2), length-M inverse transform in LDS, -> Y[array][row][q][m];
+//   k_long_pix / k_long_cp / k_long_plain   one thread per (row, m): the R-point transforms over q / j in registers,
+//                the twiddle w_W^(m q), and between them the solver's per-pixel step on the R pixels M j + m;
+//   k_long_fwd   one workgroup per (row, q <= R/2): length-M forward transforms of the produced arrays -> half-spectra
+//                (0 < q < R/2 also writes the terms of residue R - q, the conjugates of its upper half).
+// Every array is real, so only q = 0 .. R/2 exist on the frequency side (the rest are conjugates).
+// The two real arrays of an iteration are transformed separately here (no packing into one complex transform), and
+// D / D^T are applied as row-spectral multipliers eD[k] = 1 - w_W^k (a third array each way) instead of as stencils,
+// so the pixel kernel needs no neighbour from another thread.  This path trades bandwidth for simplicity: it exists
+// so that images wider than 8192 pixels run at all (row slabs of one 32768 x 32768 image), not to be fast.
+#pragma once
+#include "ddn_kernels.hpp"
+#include "ddn_long_args.hpp"
+
+namespace dlong {
+
+template <typename T>
+__device__ __forceinline__ cx<T> unit(long e, int n) {   // exp(-2 pi i e / n), 0 <= e < n
+    T s, c;
+    if constexpr (sizeof(T) == 4) sincospif(-2.0f * (float)e / (float)n, &s, &c);
+    else sincospi(-2.0 * (double)e / (double)n, &s, &c);
+    return mk<T>(c, s);
+}
+template <typename T>
+__device__ __forceinline__ size_t y_index(const LongArgs<T>& a, int arr, size_t row, int q, int m) {
+    return ((((size_t)arr * ((size_t)a.c.batch * a.c.H) + row) * (a.R / 2 + 1)) + q) * (size_t)a.M + m;
+}
+
+// ---- frequency side, inverse: half-spectra -> Y -----------------------------------------------------------
+// array 0: S0 (u); array 1: S1 (K u); array 2: eD * S0 (D u).  narr = 1: S0 only.
+template <typename T>
+__global__ void __launch_bounds__(256) k_long_inv(LongArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x, W = a.c.W, M = a.M, R = a.R, nq = R / 2 + 1;
+    RowLds<T> L(smem, M);
+    const Tw<T> tw = tw_setup(L.tw, a.twM, M, tid, nt);
+    const size_t nrows = (size_t)a.c.batch * a.c.H;
+    const size_t items = nrows * a.narr * nq;
+    for (size_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const int q = (int)(it % nq);
+        const int arr = (int)((it / nq) % a.narr);
+        const size_t row = it / ((size_t)nq * a.narr);
+        const int plane = (int)(row / a.c.H);
+        if (a.c.stop && a.c.stop[plane] >= 0) continue;
+        const SpecRow sr = spec_row(a.c.lay, plane, (int)(row - (size_t)plane * a.c.H));
+        const cx<T>* const src = arr == 1 ? a.c.S1 : a.c.S0;
+        __syncthreads();
+        for (int kap = tid; kap < M; kap += nt) {
+            const int k = R * kap + q;
+            const int kk = k <= W / 2 ? k : W - k;
+            cx<T> z = src[sr.at(kk)];
+            if (arr == 2) z = z * a.ed[kk];
+            if (kk == 0 || 2 * kk == W) z.y = (T)0;          // mean and Nyquist term of a real row are real
+            if (k > W / 2) z = cconj(z);
+            L.data[SW(pos_of_freq(a.fm, kap))] = z;
+        }
+        __syncthreads();
+        fft_inverse<T>(L.data, 1, 0, tw, a.fm, 0, tid, nt);
+        cx<T>* const y = a.Y + y_index(a, arr, row, q, 0);
+        for (int m = tid; m < M; m += nt) y[m] = L.data[SW(m)];
+    }
+}
+
+// ---- frequency side, forward: Y -> half-spectra -------------------------------------------------------------
+// narr = 3: S0 <- F(re) + conj(eD) F(s) (arrays 0 and 2), S1 <- F(im) (array 1).  narr = 1: S0 <- F(array 0).
+template <typename T>
+__global__ void __launch_bounds__(256) k_long_fwd(LongArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, nt = blockDim.x, W = a.c.W, M = a.M, R = a.R, nq = R / 2 + 1;
+    RowLds<T> L(smem, M);
+    const Tw<T> tw = tw_setup(L.tw, a.twM, M, tid, nt);
+    const size_t nrows = (size_t)a.c.batch * a.c.H;
+    const size_t items = nrows * nq;
+    for (size_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const int q = (int)(it % nq);
+        const size_t row = it / nq;
+        const int plane = (int)(row / a.c.H);
+        if (a.c.stop && a.c.stop[plane] >= 0) continue;
+        const SpecRow sr = spec_row(a.c.lay, plane, (int)(row - (size_t)plane * a.c.H));
+        // passes: (array, destination, mode) with mode 0 store, 1 store times conj(eD), 2 add
+        const int npass = a.narr == 3 ? 3 : 1;
+        for (int ps = 0; ps < npass; ++ps) {
+            const int arr = a.narr == 3 ? (ps == 0 ? 2 : (ps == 1 ? 0 : 1)) : 0;
+            const int mode = a.narr == 3 ? (ps == 0 ? 1 : (ps == 1 ? 2 : 0)) : 0;
+            cx<T>* const dst = (a.narr == 3 && ps == 2) ? a.c.S1 : a.c.S0;
+            const cx<T>* const y = a.Y + y_index(a, arr, row, q, 0);
+            __syncthreads();
+            for (int m = tid; m < M; m += nt) L.data[SW(m)] = y[m];
+            __syncthreads();
+            fft_forward<T>(L.data, 1, 0, tw, a.fm, 0, tid, nt);
+            for (int kap = tid; kap < M; kap += nt) {
+                // residues 0 and R/2 hold both halves of their own terms: keep k <= W/2.  A residue in between
+                // also produces, as conjugates, the terms of residue R - q, which no workgroup transforms.
+                int k = R * kap + q;
+                const bool upper = k > W / 2;
+                if (upper && (q == 0 || 2 * q == R)) continue;
+                cx<T> z = L.data[SW(pos_of_freq(a.fm, kap))];
+                if (upper) { k = W - k; z = cconj(z); }
+                const size_t o = sr.at(k);
+                if (mode == 1) z = mulc(z, a.ed[k]);
+                if (mode == 2) z = z + dst[o];
+                dst[o] = z;
+            }
+        }
+    }
+}
+
+// ---- pixel side helpers ------------------------------------------------------------------------------------
+// R real values at one m <-> the R/2 + 1 complex terms y[q] (twiddle w_W^(m q) included).
+template <typename T, int R>
+__device__ __forceinline__ void to_pixels(const LongArgs<T>& a, int arr, size_t row, int m, const cx<T> (&twd)[R / 2 + 1], T (&out)[R]) {
+    cx<T> v[R];
+#pragma unroll
+    for (int q = 0; q <= R / 2; ++q) v[q] = mulc(a.Y[y_index(a, arr, row, q, m)], twd[q]);   // conj twiddle on the way back
+#pragma unroll
+    for (int q = R / 2 + 1; q < R; ++q) v[q] = cconj(v[R - q]);
+    v[0].y = (T)0;
+    v[R / 2].y = (T)0;
+    Dft<T, R, true>::run(v);
+#pragma unroll
+    for (int j = 0; j < R; ++j) out[j] = v[j].x;
+}
+template <typename T, int R>
+__device__ __forceinline__ void from_pixels(const LongArgs<T>& a, int arr, size_t row, int m, const cx<T> (&twd)[R / 2 + 1], const T (&in)[R]) {
+    cx<T> v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) v[j] = mk<T>(in[j], (T)0);
+    Dft<T, R, false>::run(v);
+#pragma unroll
+    for (int q = 0; q <= R / 2; ++q) a.Y[y_index(a, arr, row, q, m)] = v[q] * twd[q];
+}
+template <typename T, int R>
+__device__ __forceinline__ void twiddles(const LongArgs<T>& a, int m, cx<T> (&twd)[R / 2 + 1]) {
+#pragma unroll
+    for (int q = 0; q <= R / 2; ++q) twd[q] = unit<T>((long)m * q, a.c.W);
+}
+
+// ---- the resolvent solvers (primal DR, primal-dual DR, ADMM): policy step on the R pixels of every m ------------
+template <typename T, class P, int R>
+__global__ void __launch_bounds__(256) k_long_pix(LongArgs<T> a, typename P::Args pa) {
+    __shared__ double red[16 * 4];
+    const int tid = threadIdx.x, nt = blockDim.x, M = a.M, W = a.c.W;
+    const size_t nrows = (size_t)a.c.batch * a.c.H;
+    for (size_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int plane = (int)(row / a.c.H);
+        if (a.c.stop && a.c.stop[plane] >= 0) continue;
+        double acc[4] = {0, 0, 0, 0};
+        for (int m = tid; m < M; m += nt) {
+            cx<T> twd[R / 2 + 1];
+            twiddles<T, R>(a, m, twd);
+            T u[R], k[R], du[R], re[R], im[R], s[R];
+            if (a.c.do_consume) {
+                to_pixels<T, R>(a, 0, row, m, twd, u);
+                to_pixels<T, R>(a, 1, row, m, twd, k);
+                to_pixels<T, R>(a, 2, row, m, twd, du);
+            }
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const size_t o = row * (size_t)W + (size_t)M * j + m;
+                T u1[1] = {u[j]}, k1[1] = {k[j]}, d1[1] = {du[j]}, r1[1], i1[1], s1[1];
+                P::template step<1>(pa, a.c.do_consume != 0, a.c.do_produce != 0, o, u1, k1, d1, r1, i1, s1, acc);
+                re[j] = r1[0]; im[j] = i1[0]; s[j] = s1[0];
+            }
+            if (a.c.do_produce) {
+                from_pixels<T, R>(a, 0, row, m, twd, re);
+                from_pixels<T, R>(a, 1, row, m, twd, im);
+                from_pixels<T, R>(a, 2, row, m, twd, s);
+            }
+        }
+        if (a.c.do_consume) {
+            block_reduce<4>(acc, red, tid, nt);
+            if (tid == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a.c.partials[row * 4 + q] = acc[q];
+            }
+        }
+    }
+}
+
+// ---- Chambolle-Pock (cp:58-92): one array each way; D z and D^T(y1 + y2) are differences of arrays the step only reads
+template <typename T, int R>
+__global__ void __launch_bounds__(256) k_long_cp(LongArgs<T> a, CpArgs<T> p) {
+    __shared__ double red[16 * 4];
+    const int tid = threadIdx.x, nt = blockDim.x, M = a.M, W = a.c.W;
+    const size_t nrows = (size_t)a.c.batch * a.c.H;
+    for (size_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        double acc[4] = {0, 0, 0, 0};
+        const size_t ro = row * (size_t)W;
+        for (int m = tid; m < M; m += nt) {
+            cx<T> twd[R / 2 + 1];
+            twiddles<T, R>(a, m, twd);
+            T in[R], out[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) in[j] = (T)0;
+            if (a.c.do_consume) to_pixels<T, R>(a, 0, row, m, twd, in);
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int n = M * j + m;
+                const size_t o = ro + n;
+                if (p.step == 0) {
+                    const T z = p.z[o], zp = p.z[ro + (n == 0 ? W - 1 : n - 1)];
+                    const T dz = z - zp;                                                      // cp:61
+                    const T b = p.b[o];
+                    const T g0 = p.y0[o] + p.s * in[j];                                       // cp:66
+                    const T g1 = p.y1[o] + p.s * dz;
+                    const T g2 = p.y2[o] + p.s * dz;
+                    T pr0;
+                    if (p.objective == 0) pr0 = soft(g0 / p.s - b, p.is); else pr0 = (g0 / p.s - b) / p.l2div;   // cp:69-72
+                    const T y0n = g0 - p.s * b - p.s * pr0;
+                    T i1, i2;
+                    iso(g1 / p.s, g2 / p.s, p.isg, i1, i2);                                   // cp:75
+                    p.y0[o] = y0n;
+                    p.y1[o] = g1 - p.s * i1;
+                    p.y2[o] = g2 - p.s * i2;
+                    out[j] = y0n;
+                } else if (a.c.do_consume) {
+                    const size_t on = ro + (n + 1 == W ? 0 : n + 1);
+                    const T dty = (p.y1[o] + p.y2[o]) - (p.y1[on] + p.y2[on]);                // D^T(y1 + y2), cp:79
+                    const T x = p.x[o];
+                    const T xn = clip01(x - p.t * (in[j] + dty));                             // cp:83-86
+                    const T zn = (T)2 * xn - x;                                               // cp:87
+                    const T d = xn - p.b[o];                                                  // cp:96
+                    acc[0] += (double)t_abs(d); acc[1] += (double)d * (double)d;
+                    p.x[o] = xn;
+                    p.z[o] = zn;
+                    out[j] = zn;
+                } else {
+                    out[j] = p.z[o];
+                }
+            }
+            if (a.c.do_produce) from_pixels<T, R>(a, 0, row, m, twd, out);
+        }
+        if (p.step == 1 && a.c.do_consume) {
+            block_reduce<4>(acc, red, tid, nt);
+            if (tid == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a.c.partials[row * 4 + q] = acc[q];
+            }
+        }
+    }
+}
+
+// ---- plain transforms: src -> Y (forward) or Y -> dst * scale (inverse)
+template <typename T, int R>
+__global__ void __launch_bounds__(256) k_long_plain(LongArgs<T> a, const T* src, T* dst, T scale) {
+    const int tid = threadIdx.x, nt = blockDim.x, M = a.M, W = a.c.W;
+    const size_t nrows = (size_t)a.c.batch * a.c.H;
+    for (size_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        for (int m = tid; m < M; m += nt) {
+            cx<T> twd[R / 2 + 1];
+            twiddles<T, R>(a, m, twd);
+            T v[R];
+            if (src) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) v[j] = src[row * (size_t)W + (size_t)M * j + m];
+                from_pixels<T, R>(a, 0, row, m, twd, v);
+            } else {
+                to_pixels<T, R>(a, 0, row, m, twd, v);
+#pragma unroll
+                for (int j = 0; j < R; ++j) dst[row * (size_t)W + (size_t)M * j + m] = v[j] * scale;
+            }
+        }
+    }
+}
+
+}  // namespace dlong

@@ -1,0 +1,24 @@
+// Argument block and launcher declarations of the long-row path (ddn_long.hpp / ddn_long.hip), kept apart from the
+// kernels so that the host translation unit does not compile them.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ddn_kernels.hpp"
+
+template <typename T>
+struct LongArgs {
+    RowCommon<T> c;      // H = rows of this launch per image, W, batch, lay, S0, S1, stop, partials, do_consume, do_produce
+    cx<T>* Y;            // [3 arrays][batch * H rows][R/2 + 1][M]
+    const cx<T>* twM;    // twiddle table of length M (layout of make_table)
+    const cx<T>* ed;     // row-spectral D: eD[k], k = 0 .. W/2
+    FftDesc fm;          // the length-M transform
+    int R, M;
+    int narr;            // arrays crossing per direction: 3 (u, K u, D u) / (re, im, s) for the resolvent solvers, 1 otherwise
+};
+
+template <typename T, class P>
+int long_row_launch(hipStream_t st, int num_cu, const LongArgs<T>& a, const typename P::Args& pa);
+template <typename T>
+int long_cp_launch(hipStream_t st, int num_cu, const LongArgs<T>& a, const CpArgs<T>& pa);
+template <typename T>
+int long_plain_launch(hipStream_t st, int num_cu, const LongArgs<T>& a, const T* src, T* dst, T scale);

@@ -1,0 +1,108 @@
+"""Rows wider than 8192 pixels (the row transform split W = R x M over three kernels, csrc/ddn_long.hpp) against the CPU
+oracle: the 16 x 32768 and 32768 x 32 cases, all four solvers, and the same code path forced onto small images
+(DDN_FORCE_LONG_ROWS) so that float64 and odd splits are covered at sizes the oracle finishes in a moment."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ddn_oracle as O  # checker only
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import convex_optimization_amd as pkg
+    from convex_optimization_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return pkg
+
+
+@pytest.fixture(autouse=True)
+def _fresh_plans():
+    from convex_optimization_amd import plan as P
+    P.clear_plan_cache()      # the cache key does not know about DDN_FORCE_LONG_ROWS
+    yield
+    P.clear_plan_cache()
+
+
+def rel(a, b):
+    return O.rel_l2(np.asarray(a), np.asarray(b))
+
+
+def _problem(golden_dir, H, W, kname, dt, seed=0):
+    k = np.load(os.path.join(golden_dir, "kernels.npz"))
+    kern = torch.from_numpy(k[kname])
+    torch.manual_seed(seed)
+    img = torch.rand(1, H, W, dtype=dt)
+    b = O.add_gaussian_noise(O.circular_convolve2d(img, kern), 0.0, 0.05)[0].to(dt)
+    stC = (torch.rand(H, W, dtype=dt), torch.rand(H, W, dtype=dt), torch.rand(3, H, W, dtype=dt))
+    stA = tuple(torch.clamp(torch.randn(s, dtype=torch.float32), 0, 1).to(dt) for s in [(H, W), (H, W), (3, H, W), (3, H, W)])
+    stP = (torch.rand(H, W, dtype=dt), torch.rand(3, H, W, dtype=dt))
+    return kern, b, stC, stA, stP
+
+
+def _all_four(pkg, kern, b, stC, stA, stP, N, eig=None, cp=True):
+    ea = (lambda t, s: None) if eig is None else eig
+    out = {}
+    if cp:
+        out["cp"] = (pkg.chambolle_pock_solver(b[None], kern, t=0.3, s=0.3, max_iter=N + 1, init_state=stC, eig_arrays=ea(1, 1)),
+                     O.chambolle_pock(b[None], kern, t=0.3, s=0.3, max_iter=N + 1, init_state=stC))
+    for obj in ("l1", "l2"):
+        out["admm_" + obj] = (pkg.admm_solver(b, obj, kernel=kern, niters=N + 1, tol=-1.0, init_state=stA, eig_arrays=ea(1, 1)),
+                              O.admm_solver(b, obj, kernel=kern, niters=N + 1, tol=-1.0, init_state=stA))
+    out["pdr"] = (pkg.primal_dr_splitting("l1", kern, b, niters=N, loss_function=pkg.core.mse, tol=-1.0, eig_arrays=ea(2.0, None)),
+                  O.primal_dr_splitting("l1", kern, b, niters=N))
+    out["pddr"] = (pkg.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP, tol=-1.0, eig_arrays=ea(3, 3)),
+                   O.primal_dual_dr_splitting(b, kern, niters=N + 1, init_state=stP))
+    return {k: rel(g.numpy(), r.numpy()) for k, (g, r) in out.items()}
+
+
+@pytest.mark.parametrize("H,W,kname,R", [(64, 64, "gauss9", 1), (48, 80, "motion15_45", 2), (24, 96, "gauss5", 4), (32, 128, "gauss9", 8), (16, 256, "gauss9", 16),
+                                         (16, 8192, "motion15_45", 8)])
+def test_forced_split_rows_fp32_vs_oracle(pkg, golden_dir, monkeypatch, H, W, kname, R):
+    """The split row path forced onto small images, W = R x M for every supported R (1 = the smallest that fits):
+    all four solvers, N = 10 and 40."""
+    monkeypatch.setenv("DDN_FORCE_LONG_ROWS", str(R))
+    kern, b, stC, stA, stP = _problem(golden_dir, H, W, kname, torch.float32)
+    for N in (10, 40):
+        res = _all_four(pkg, kern, b, stC, stA, stP, N)
+        bad = {k: v for k, v in res.items() if not v < 1e-5}
+        assert not bad, (N, res)
+    # operator applications through the plain split transforms
+    x = torch.rand(H, W)
+    ops, oo = pkg.DeblurDenoiseOperators(kern, b, 2.0, 0.5), O.DeblurDenoiseOperators(kern, b, 2.0, 0.5)
+    for nm in ("apply_K", "apply_KTrans", "invert_matrix", "apply_Mat"):
+        got, want = getattr(ops, nm)(x).real.numpy(), getattr(oo, nm)(x).real.numpy()
+        assert np.abs(got - want).max() < 5e-6, nm
+    ops.close()
+
+
+def test_forced_split_rows_fp64_vs_oracle(pkg, golden_dir, monkeypatch):
+    """float64 with the reference's complex64-derived eigen arrays handed in: 1e-11 (the three resolvent solvers; for
+    Chambolle-Pock the split row path supports the built-in eigenvalues only)."""
+    monkeypatch.setenv("DDN_FORCE_LONG_ROWS", "1")
+    kern, b, stC, stA, stP = _problem(golden_dir, 64, 64, "gauss9", torch.float64)
+
+    def eig(t, s):
+        ops = O.DeblurDenoiseOperators(kern, b, t, s)
+        return {"K": ops.eig_arry_K, "D": ops.eig_arry_D1, "M": ops.eig_vals_mat}
+    res = _all_four(pkg, kern, b, stC, stA, stP, 20, eig=eig, cp=False)
+    bad = {k: v for k, v in res.items() if not v < 1e-11}
+    assert not bad, res
+    from convex_optimization_amd._lib import DdnError
+    with pytest.raises(DdnError):
+        pkg.chambolle_pock_solver(b[None], kern, max_iter=3, init_state=stC, eig_arrays=eig(1, 1))
+
+
+@pytest.mark.parametrize("H,W", [(16, 32768), (32768, 32), (16, 16384)])
+def test_rows_and_columns_of_32768_vs_oracle(pkg, golden_dir, H, W):
+    """The line lengths of the 32768 x 32768 configuration: 32768-pixel rows take the split row transform (8 x 4096),
+    32768-row columns the split column transform; all four solvers, N = 10, fp32 <= 1e-5 against the oracle."""
+    kern, b, stC, stA, stP = _problem(golden_dir, H, W, "motion15_45", torch.float32)
+    res = _all_four(pkg, kern, b, stC, stA, stP, 10)
+    bad = {k: v for k, v in res.items() if not v < 1e-5}
+    assert not bad, res

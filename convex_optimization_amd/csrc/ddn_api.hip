@@ -326,7 +326,7 @@ int plan_alloc(ddn_plan* p) {
     int rc;
     if ((rc = make_table<T>(p->W, (cx<T>**)&p->twW))) return rc;
     if ((rc = make_table<T>(p->H, (cx<T>**)&p->twH))) return rc;
-    if (sizeof(T) == 4 && (p->W == 4096 || p->H == 4096)) {
+    if (sizeof(T) == 4 && (p->W == 4096 || p->H == 4096 || p->long_M == 4096)) {
         // lane l: w^(l c), c = 0..7, then w^(8 l a), a = 0..7, w = exp(-2 pi i / 4096)
         std::vector<cx<float>> tab(64 * 16);
         const long double tp = -2.0L * 3.14159265358979323846264338327950288L / 4096.0L;
@@ -659,6 +659,7 @@ int long_args(ddn_plan* p, const RowCommon<T>& c, int narr, LongArgs<T>& a) {
     a.twM = (const cx<T>*)p->twL;
     a.ed = p->injected ? (const cx<T>*)p->eDrow : (const cx<T>*)p->edL;
     a.fm = p->fl;
+    a.wtw = getenv("DDN_NO_WAVE_ROWS") ? nullptr : (const cx<float>*)p->wtw;
     a.R = p->long_R; a.M = p->long_M;
     a.narr = narr;
     return DDN_OK;

@@ -6,23 +6,27 @@ namespace {
 
 template <typename T>
 int long_inv(hipStream_t st, int num_cu, const LongArgs<T>& a) {
+    if constexpr (sizeof(T) == 4) {
+        if (long_wave_ok(a)) return long_wave_launch(st, num_cu, a, true);
+    }
     auto fn = dlong::k_long_inv<T>;
     int rc = ensure_lds_attr((const void*)fn);
     if (rc) return rc;
-    const size_t items = (size_t)a.c.batch * a.c.H * a.narr * (a.R / 2 + 1);
-    const int grid = (int)std::min<size_t>(items, (size_t)num_cu * 8);
-    hipLaunchKernelGGL(fn, dim3(std::max(grid, 1)), dim3(256), row_lds_bytes<T>(a.M, 1), st, a);
+    const int grid = dlong::long_grid((size_t)a.c.batch * a.c.H, a.narr * (a.R / 2 + 1), num_cu);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), row_lds_bytes<T>(a.M, 1), st, a);
     HIPCHK(hipGetLastError());
     return DDN_OK;
 }
 template <typename T>
 int long_fwd(hipStream_t st, int num_cu, const LongArgs<T>& a) {
+    if constexpr (sizeof(T) == 4) {
+        if (long_wave_ok(a)) return long_wave_launch(st, num_cu, a, false);
+    }
     auto fn = dlong::k_long_fwd<T>;
     int rc = ensure_lds_attr((const void*)fn);
     if (rc) return rc;
-    const size_t items = (size_t)a.c.batch * a.c.H * (a.R / 2 + 1);
-    const int grid = (int)std::min<size_t>(items, (size_t)num_cu * 8);
-    hipLaunchKernelGGL(fn, dim3(std::max(grid, 1)), dim3(256), row_lds_bytes<T>(a.M, 1), st, a);
+    const int grid = dlong::long_grid((size_t)a.c.batch * a.c.H, a.R / 2 + 1, num_cu);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), row_lds_bytes<T>(a.M, 1), st, a);
     HIPCHK(hipGetLastError());
     return DDN_OK;
 }

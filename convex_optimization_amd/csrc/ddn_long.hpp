@@ -34,6 +34,29 @@ __device__ __forceinline__ size_t y_index(const LongArgs<T>& a, int arr, size_t 
     return ((((size_t)arr * ((size_t)a.c.batch * a.c.H) + row) * (a.R / 2 + 1)) + q) * (size_t)a.M + m;
 }
 
+// Work split of the two frequency-side kernels.  The `per_row` workgroups of one row (one per residue q, and per
+// array) touch interleaved elements of the same cache lines of the row's half-spectra: element R kappa + q sits
+// between those of the other residues.  Workgroup b runs on XCD b % 8 and only that XCD's L2 can serve a line to
+// several of them (or merge their partial-line writes), so the per_row workgroups of a row take consecutive slots
+// of ONE XCD and run at the same time.  The grid is 8 * per_row * S workgroups (long_grid below).
+struct RowSlot {
+    size_t row, step;
+    int sub;
+};
+__device__ __forceinline__ RowSlot row_slot(int per_row) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, S = (int)(gridDim.x >> 3) / per_row;
+    RowSlot r;
+    r.sub = j % per_row;
+    r.row = (size_t)(j / per_row) * 8 + x;
+    r.step = (size_t)8 * S;
+    return r;
+}
+inline int long_grid(size_t nrows, int per_row, int num_cu) {
+    const size_t want = std::max<size_t>(1, (size_t)num_cu / per_row);            // slots per XCD: about 8 workgroups per CU in all
+    const size_t S = std::max<size_t>(1, std::min<size_t>(want, (nrows + 7) / 8));
+    return (int)(8 * per_row * S);
+}
+
 // ---- frequency side, inverse: half-spectra -> Y -----------------------------------------------------------
 // array 0: S0 (u); array 1: S1 (K u); array 2: eD * S0 (D u).  narr = 1: S0 only.
 template <typename T>
@@ -43,11 +66,9 @@ __global__ void __launch_bounds__(256) k_long_inv(LongArgs<T> a) {
     RowLds<T> L(smem, M);
     const Tw<T> tw = tw_setup(L.tw, a.twM, M, tid, nt);
     const size_t nrows = (size_t)a.c.batch * a.c.H;
-    const size_t items = nrows * a.narr * nq;
-    for (size_t it = blockIdx.x; it < items; it += gridDim.x) {
-        const int q = (int)(it % nq);
-        const int arr = (int)((it / nq) % a.narr);
-        const size_t row = it / ((size_t)nq * a.narr);
+    const RowSlot rs = row_slot(a.narr * nq);
+    const int q = rs.sub % nq, arr = rs.sub / nq;
+    for (size_t row = rs.row; row < nrows; row += rs.step) {
         const int plane = (int)(row / a.c.H);
         if (a.c.stop && a.c.stop[plane] >= 0) continue;
         const SpecRow sr = spec_row(a.c.lay, plane, (int)(row - (size_t)plane * a.c.H));
@@ -78,10 +99,9 @@ __global__ void __launch_bounds__(256) k_long_fwd(LongArgs<T> a) {
     RowLds<T> L(smem, M);
     const Tw<T> tw = tw_setup(L.tw, a.twM, M, tid, nt);
     const size_t nrows = (size_t)a.c.batch * a.c.H;
-    const size_t items = nrows * nq;
-    for (size_t it = blockIdx.x; it < items; it += gridDim.x) {
-        const int q = (int)(it % nq);
-        const size_t row = it / nq;
+    const RowSlot rs = row_slot(nq);
+    const int q = rs.sub;
+    for (size_t row = rs.row; row < nrows; row += rs.step) {
         const int plane = (int)(row / a.c.H);
         if (a.c.stop && a.c.stop[plane] >= 0) continue;
         const SpecRow sr = spec_row(a.c.lay, plane, (int)(row - (size_t)plane * a.c.H));

@@ -12,6 +12,7 @@ struct LongArgs {
     const cx<T>* twM;    // twiddle table of length M (layout of make_table)
     const cx<T>* ed;     // row-spectral D: eD[k], k = 0 .. W/2
     FftDesc fm;          // the length-M transform
+    const cx<float>* wtw; // per-lane twiddles of the register-resident 4096-point transform (M = 4096, float) or null
     int R, M;
     int narr;            // arrays crossing per direction: 3 (u, K u, D u) / (re, im, s) for the resolvent solvers, 1 otherwise
 };
@@ -22,3 +23,7 @@ template <typename T>
 int long_cp_launch(hipStream_t st, int num_cu, const LongArgs<T>& a, const CpArgs<T>& pa);
 template <typename T>
 int long_plain_launch(hipStream_t st, int num_cu, const LongArgs<T>& a, const T* src, T* dst, T scale);
+
+// M = 4096, float: the frequency-side kernels with wave-resident transforms (ddn_longw.hip)
+bool long_wave_ok(const LongArgs<float>& a);
+int long_wave_launch(hipStream_t st, int num_cu, const LongArgs<float>& a, bool inverse);

@@ -62,7 +62,7 @@ def _all_four(pkg, kern, b, stC, stA, stP, N, eig=None, cp=True):
 
 
 @pytest.mark.parametrize("H,W,kname,R", [(64, 64, "gauss9", 1), (48, 80, "motion15_45", 2), (24, 96, "gauss5", 4), (32, 128, "gauss9", 8), (16, 256, "gauss9", 16),
-                                         (16, 8192, "motion15_45", 8)])
+                                         (16, 8192, "motion15_45", 8), (16, 8192, "gauss9", 2)])
 def test_forced_split_rows_fp32_vs_oracle(pkg, golden_dir, monkeypatch, H, W, kname, R):
     """The split row path forced onto small images, W = R x M for every supported R (1 = the smallest that fits):
     all four solvers, N = 10 and 40."""

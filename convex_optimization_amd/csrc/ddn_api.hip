@@ -160,6 +160,10 @@ struct ddn_plan {
     int num_cu = 256;
     // device buffers (typed by dtype)
     void* twW = nullptr;
+    // a plan of the row-slab decomposition that holds the multipliers of its own spectral tiles only (ddn_plan_create_slab):
+    // eK and G cover tiles [slab_lo, slab_lo + slab_n); no S0 / S1 / Gc / tmp_mult; only the ddn_slab_* entries run on it
+    bool restricted = false;
+    int slab_lo = 0, slab_n = 0;
     void* wtw = nullptr;     // per-lane twiddles of the register-resident 4096-point transform (float) or null
     void* wtwH = nullptr;    // the same table for the H = 512 / 1024 / 2048 column transforms, or null
     void* wtwW = nullptr;    // per-lane twiddles w_W^(lane k), k < W / 64, of the W = 512 / 1024 / 2048 row transforms, or null
@@ -362,7 +366,7 @@ int plan_alloc(ddn_plan* p) {
         HIPCHK(hipMemcpy(p->edL, ed.data(), ed.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
     }
     if ((rc = alloc_col_tables<T>(p))) return rc;
-    if ((rc = alloc_spec<T>(p))) return rc;
+    if (!p->restricted && (rc = alloc_spec<T>(p))) return rc;
     const int Wt = p->Wh + 64;
     HIPCHK(hipMalloc(&p->eDrow, (size_t)Wt * sizeof(cx<T>)));
     HIPCHK(hipMalloc(&p->ed2, (size_t)Wt * sizeof(T)));
@@ -844,9 +848,99 @@ int set_kernel_impl(ddn_plan* p, const double* taps, int kh, int kw, bool as_con
     return rc;
 }
 
+// eK of the plan's own tile range straight from the taps (a plan of ddn_plan_create_slab holds no whole plane to
+// transform).  The impulse response of set_kernel_impl is separable in position: tap (u, v) sits at row rpos[u],
+// column cpos[v], so  eK[k1][k2] = sum_u w_H^(k1 rpos[u]) * sum_v tap[u][v] w_W^(k2 cpos[v]):  k_taps_cols builds
+// the inner sums for the local columns, k_taps_eK the outer one; both in double, rounded once.
+__global__ void k_taps_cols(const double* taps, const int* cpos, int kh, int kw, int W, int col_lo, int ncols, double2* t1) {
+    const int total = kh * ncols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int u = i / ncols, c = i - u * ncols;
+        const long long k2 = col_lo + c;
+        double re = 0, im = 0;
+        for (int v = 0; v < kw; ++v) {
+            if (cpos[v] < 0) continue;
+            const long long m = (k2 * cpos[v]) % W;
+            double sn, cs_;
+            sincospi(-2.0 * (double)m / (double)W, &sn, &cs_);
+            re += taps[u * kw + v] * cs_;
+            im += taps[u * kw + v] * sn;
+        }
+        t1[i] = make_double2(re, im);
+    }
+}
+template <typename T>
+__global__ void k_taps_eK(const double2* t1, const int* rpos, int kh, int H, int ncols, cx<T>* out, SpecLayout lay, ColMap cm) {
+    const size_t total = (size_t)H * ncols;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k1 = (int)(i / ncols), c = (int)(i - (size_t)k1 * ncols);
+        double re = 0, im = 0;
+        for (int u = 0; u < kh; ++u) {
+            if (rpos[u] < 0) continue;
+            const long long m = ((long long)k1 * rpos[u]) % H;
+            double sn, cs_;
+            sincospi(-2.0 * (double)m / (double)H, &sn, &cs_);
+            const double2 a = t1[(size_t)u * ncols + c];
+            re += a.x * cs_ - a.y * sn;
+            im += a.x * sn + a.y * cs_;
+        }
+        out[spec_row(lay, 0, colpos_of_freq(cm, k1)).at(c)] = mk<T>((T)re, (T)im);
+    }
+}
+
+template <typename T>
+int set_kernel_local(ddn_plan* p, const double* taps, int kh, int kw) {
+    const int H = p->H, W = p->W;
+    const int col_lo = p->slab_lo << p->cs, ncols = std::min(p->Wh - col_lo, p->slab_n << p->cs);
+    if (ncols <= 0) return DDN_OK;
+    // correlation centred at (kh/2, kw/2) (eig:41-56); taps rounded to float first (eig:49), then to the plan's type
+    std::vector<double> tp((size_t)kh * kw);
+    for (size_t i = 0; i < tp.size(); ++i) tp[i] = (double)(T)(float)taps[i];
+    std::vector<int> pos(kh + kw);
+    for (int u = 0; u < kh; ++u) pos[u] = (int)((((long)kh / 2 - u) % H + H) % H);
+    for (int v = 0; v < kw; ++v) pos[kh + v] = (int)((((long)kw / 2 - v) % W + W) % W);
+    double* dt = nullptr;
+    int* dpos = nullptr;
+    double2* t1 = nullptr;
+    HIPCHK(hipMalloc((void**)&dt, tp.size() * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&dpos, pos.size() * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&t1, (size_t)kh * ncols * sizeof(double2)));
+    int rc = DDN_OK;
+    hipError_t e = hipMemcpyAsync(dt, tp.data(), tp.size() * sizeof(double), hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dpos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_taps_cols, dim3(ew_grid((size_t)kh * ncols)), dim3(256), 0, p->stream, dt, dpos + kh, kh, kw, W, col_lo, ncols, t1);
+        SpecLayout lay = layout_of(p);
+        lay.ntile = p->slab_n;
+        hipLaunchKernelGGL(k_taps_eK<T>, dim3(ew_grid((size_t)H * ncols)), dim3(256), 0, p->stream, t1, dpos, kh, H, ncols, (cx<T>*)p->eK, lay, colmap<T>(p));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);      // tp / pos are read by the copies until here
+    if (e != hipSuccess) rc = fail(DDN_E_HIP, hipGetErrorString(e));
+    (void)hipFree(dt);
+    (void)hipFree(dpos);
+    (void)hipFree(t1);
+    return rc;
+}
+
 template <typename T>
 int set_resolvent_impl(ddn_plan* p, double cK, double cD, const void* M_dev, int cdtype) {
     const double scale = 1.0 / ((double)p->H * (double)p->W);
+    if (p->restricted) {
+        if (M_dev) return fail(DDN_E_UNSUPPORTED, "set_resolvent: a plan of ddn_plan_create_slab takes no injected eigen arrays");
+        if (!p->have_K) return fail(DDN_E_STATE, "set_resolvent: no blur kernel set");
+        const int col_lo = p->slab_lo << p->cs, ncols = std::min(p->Wh - col_lo, p->slab_n << p->cs);
+        if (ncols > 0) {
+            SpecLayout lay = layout_of(p);
+            lay.ntile = p->slab_n;
+            hipLaunchKernelGGL(k_make_G<T>, dim3(ew_grid((size_t)p->H * ncols)), dim3(256), 0, p->stream, (const cx<T>*)p->eK, (const T*)p->ed2 + col_lo, (T*)p->G,
+                               p->H, ncols, lay, (T)cK, (T)cD, (T)scale);
+            HIPCHK(hipGetLastError());
+        }
+        p->have_G = true;
+        p->g_cK = cK; p->g_cD = cD;
+        return DDN_OK;
+    }
     if (M_dev) {
         int rc = import_full<T>(p, M_dev, cdtype, 1, 0, scale, (cx<T>*)p->Gc, (T*)p->G);
         if (rc) return rc;
@@ -1240,6 +1334,8 @@ template <typename T, int MODE>
 int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles, int conj_mult, int nblocks) {
     if (!p->have_K || (MODE == COL_RES2 && !p->have_G)) return fail(DDN_E_STATE, "slab_cols: operators not set");
     if (ntiles == 0) return DDN_OK;
+    if (p->restricted && (tile_lo < p->slab_lo || tile_lo + ntiles > p->slab_lo + p->slab_n))
+        return fail(DDN_E_ARG, "slab_cols: tiles outside the range given to ddn_slab_restrict");
     constexpr int NS = MODE == COL_RES2 ? 2 : 1;
     const T scale = MODE == COL_MUL ? (T)(1.0 / ((double)p->H * (double)p->W)) : (T)1;
     const size_t C = (size_t)1 << p->cs;
@@ -1305,7 +1401,7 @@ int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles, int conj_mu
     p->slab_pitch = pitch;
     p->rb_shift = sh;
     p->rb_extra = extra_rows;
-    const size_t off = (size_t)tile_lo * tile_elems;
+    const size_t off = (size_t)(tile_lo - p->slab_lo) * tile_elems;   // slab_lo: first tile the plan holds multipliers of (0 unless ddn_slab_restrict)
     if (MODE == COL_MUL) return col_stage<T, COL_MUL>(p, 1, (const cx<T>*)p->eK + off, nullptr, nullptr, conj_mult, scale, no_loss());
     return col_stage<T, COL_RES2>(p, 1, (const cx<T>*)p->eK + off, (const T*)p->G + off, p->injected ? (const cx<T>*)p->Gc + off : nullptr, 0, (T)1, no_loss());
 }
@@ -1410,13 +1506,14 @@ extern "C" {
 int ddn_version(void) { return 200; }
 const char* ddn_last_error(void) { return ddn_err().c_str(); }
 
-int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* stream) {
+static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, void* stream, bool restricted) {
     if (!out || H < 1 || W < 2 || batch < 1 || (dtype != DDN_F32 && dtype != DDN_F64)) return fail(DDN_E_ARG, "plan_create: bad arguments");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DDN_E_HIP, "plan_create: no HIP device");
     ddn_plan* p = new ddn_plan();
     p->H = H; p->W = W; p->batch = batch; p->dtype = dtype; p->stream = (hipStream_t)stream;
     p->Wh = W / 2 + 1;
+    p->restricted = restricted;
     (void)hipGetDevice(&p->device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->num_cu = prop.multiProcessorCount;
@@ -1461,6 +1558,34 @@ int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* st
     return DDN_OK;
 }
 
+int ddn_plan_create(ddn_plan** out, int H, int W, int batch, int dtype, void* stream) { return plan_create_impl(out, H, W, batch, dtype, stream, false); }
+
+int ddn_plan_create_slab(ddn_plan** out, int H, int W, int dtype, void* stream) { return plan_create_impl(out, H, W, 1, dtype, stream, true); }
+
+int ddn_slab_restrict(ddn_plan* p, int tile_lo, int n_tiles_local) {
+    if (!p) return fail(DDN_E_ARG, "null plan");
+    if (!p->restricted) return fail(DDN_E_STATE, "slab_restrict: not a plan of ddn_plan_create_slab");
+    if (tile_lo < 0 || n_tiles_local < 0 || tile_lo + n_tiles_local > p->ntile) return fail(DDN_E_ARG, "slab_restrict: tile range outside the plan");
+    for (void** q : {&p->eK, &p->G}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    p->slab_lo = tile_lo;
+    p->slab_n = n_tiles_local;
+    p->have_K = p->have_G = false;
+    const size_t m = std::max<size_t>(1, (size_t)n_tiles_local * (((size_t)(p->H + p->tile_pad_rows)) << p->cs));
+    const size_t esz = p->dtype == DDN_F32 ? sizeof(float) : sizeof(double);
+    HIPCHK(hipMalloc(&p->eK, m * 2 * esz));
+    HIPCHK(hipMalloc(&p->G, m * esz));
+    HIPCHK(hipMemsetAsync(p->eK, 0, m * 2 * esz, p->stream));
+    HIPCHK(hipMemsetAsync(p->G, 0, m * esz, p->stream));
+    return DDN_OK;
+}
+
+// the entries that work on whole planes held by the plan refuse a plan that holds none
+#define DDN_WHOLE_PLANE(p, name) \
+    if ((p) && (p)->restricted) return fail(DDN_E_STATE, name ": this plan holds only the multipliers of a tile range (ddn_plan_create_slab); use the ddn_slab_* entries")
+
 int ddn_plan_destroy(ddn_plan* p) {
     if (!p) return DDN_OK;
     void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->twL, p->edL, p->Ylong, p->nyqd, p->ssim_part, p->ssim_val, p->ssim_prev, p->nyq_taps, p->eKc, p->ctab, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
@@ -1481,6 +1606,7 @@ int ddn_plan_set_stream(ddn_plan* p, void* stream) {
 }
 
 int ddn_plan_tune(ddn_plan* p, int cols_per_block, int split_A, int col_threads) {
+    DDN_WHOLE_PLANE(p, "plan_tune");
     if (!p) return fail(DDN_E_ARG, "null plan");
     if (p->have_K) return fail(DDN_E_STATE, "plan_tune must precede set_kernel / set_eig");
     if (split_A > 0 && p->H % split_A) return fail(DDN_E_ARG, "plan_tune: split_A does not divide H");
@@ -1501,6 +1627,15 @@ int ddn_plan_tune(ddn_plan* p, int cols_per_block, int split_A, int col_threads)
 
 int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
     if (!p || !taps || kh < 1 || kw < 1) return fail(DDN_E_ARG, "set_kernel: bad arguments");
+    if (p->restricted) {
+        if (!p->eK) return fail(DDN_E_STATE, "set_kernel: call ddn_slab_restrict first");
+        int rcl = p->dtype == DDN_F32 ? set_kernel_local<float>(p, taps, kh, kw) : set_kernel_local<double>(p, taps, kh, kw);
+        if (rcl) return rcl;
+        p->have_K = true;
+        p->injected = false;
+        p->eKc_ok = p->Gcm_ok = p->ctab_ok = false;      // the tile-generic column kernels only
+        return DDN_OK;
+    }
     int rc = p->dtype == DDN_F32 ? set_kernel_impl<float>(p, taps, kh, kw, false, (cx<float>*)p->eK)
                                  : set_kernel_impl<double>(p, taps, kh, kw, false, (cx<double>*)p->eK);
     if (rc) return rc;
@@ -1519,6 +1654,7 @@ int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
 }
 
 int ddn_plan_set_eig(ddn_plan* p, const void* eigK, const void* eigD, int cdtype) {
+    DDN_WHOLE_PLANE(p, "set_eig");
     if (!p || !eigK) return fail(DDN_E_ARG, "set_eig: bad arguments");
     int rc;
     if (p->dtype == DDN_F32) rc = import_full<float>(p, eigK, cdtype, 0, 0, 1.0, (cx<float>*)p->eK, nullptr);
@@ -1580,6 +1716,7 @@ int ddn_plan_set_ssim(ddn_plan* p, const float* g11_host, double max_val, double
 }
 
 int ddn_plan_get_eigK(ddn_plan* p, void* out_dev) {
+    DDN_WHOLE_PLANE(p, "get_eigK");
     if (!p || !out_dev) return fail(DDN_E_ARG, "get_eigK: bad arguments");
     if (!p->have_K) return fail(DDN_E_STATE, "get_eigK: no blur kernel set");
     const size_t total = (size_t)p->H * p->W;
@@ -1592,11 +1729,13 @@ int ddn_plan_get_eigK(ddn_plan* p, void* out_dev) {
 }
 
 int ddn_apply(ddn_plan* p, int op, const void* x, void* y) {
+    DDN_WHOLE_PLANE(p, "apply");
     if (!p || !x || !y) return fail(DDN_E_ARG, "apply: bad arguments");
     return p->dtype == DDN_F32 ? apply_impl<float>(p, op, x, y) : apply_impl<double>(p, op, x, y);
 }
 
 int ddn_apply_multiplier(ddn_plan* p, const void* mult, int cdtype, int flags, const void* x, void* y) {
+    DDN_WHOLE_PLANE(p, "apply_multiplier");
     if (!p || !mult || !x || !y) return fail(DDN_E_ARG, "apply_multiplier: bad arguments");
     int rc;
     if (p->dtype == DDN_F32) {
@@ -1608,6 +1747,7 @@ int ddn_apply_multiplier(ddn_plan* p, const void* mult, int cdtype, int flags, c
 }
 
 int ddn_circular_convolve2d(ddn_plan* p, const double* taps, int kh, int kw, const void* image, void* out) {
+    DDN_WHOLE_PLANE(p, "circular_convolve2d");
     if (!p || !taps || !image || !out) return fail(DDN_E_ARG, "circular_convolve2d: bad arguments");
     if (kh > p->H || kw > p->W) return fail(DDN_E_ARG, "circular_convolve2d: kernel larger than the image");
     int rc;
@@ -1679,6 +1819,7 @@ int ddn_reduce_static(int dtype, const void* x, const void* y, size_t n_per_imag
 }
 
 int ddn_cp_run(ddn_plan* p, void* x, void* z, void* y, const void* b, double t, double s, double gamma, int objective, int n_iters, double* ring) {
+    DDN_WHOLE_PLANE(p, "cp_run");
     if (!p || !x || !z || !y || !b || n_iters < 0) return fail(DDN_E_ARG, "cp_run: bad arguments");
     if (objective != DDN_OBJ_L1 && objective != DDN_OBJ_L2) return fail(DDN_E_ARG, "Invalid objective function. Choose 'l1' or 'l2'.");
     p->ev_row.clear(); p->ev_col.clear(); p->ev_used = 0;
@@ -1688,6 +1829,7 @@ int ddn_cp_run(ddn_plan* p, void* x, void* z, void* y, const void* b, double t, 
 
 int ddn_admm_run(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b, double t, double rho, double gamma, int objective, int n_iters,
                  int tol_kind, double tol, int first_loss_iter, double* ring, int* iters_done, void* sol) {
+    DDN_WHOLE_PLANE(p, "admm_run");
     if (!p || !u || !w || !y || !z || !b || n_iters < 0) return fail(DDN_E_ARG, "admm_run: bad arguments");
     if (objective != DDN_OBJ_L1 && objective != DDN_OBJ_L2) return fail(DDN_E_ARG, "Invalid objective function. Choose 'l1' or 'l2'.");
     p->ev_row.clear(); p->ev_col.clear(); p->ev_used = 0;
@@ -1697,6 +1839,7 @@ int ddn_admm_run(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b,
 
 int ddn_pdr_run(ddn_plan* p, void* z1, void* z2, const void* b, double t, double rho, double gamma, int objective, int n_iters,
                 int tol_kind, double tol, int first_loss_iter, double* ring, int* iters_done) {
+    DDN_WHOLE_PLANE(p, "pdr_run");
     if (!p || !z1 || !z2 || !b || n_iters < 0) return fail(DDN_E_ARG, "pdr_run: bad arguments");
     p->ev_row.clear(); p->ev_col.clear(); p->ev_used = 0;
     return p->dtype == DDN_F32 ? pdr_run_impl<float>(p, z1, z2, b, t, rho, gamma, objective, n_iters, tol_kind, tol, first_loss_iter, ring, iters_done)
@@ -1705,6 +1848,7 @@ int ddn_pdr_run(ddn_plan* p, void* z1, void* z2, const void* b, double t, double
 
 int ddn_pddr_run(ddn_plan* p, void* pp, void* q, const void* b, double t, double rho, double gamma, int n_iters,
                  int tol_kind, double tol, int first_loss_iter, double* ring, int* iters_done) {
+    DDN_WHOLE_PLANE(p, "pddr_run");
     if (!p || !pp || !q || !b || n_iters < 0) return fail(DDN_E_ARG, "pddr_run: bad arguments");
     p->ev_row.clear(); p->ev_col.clear(); p->ev_used = 0;
     return p->dtype == DDN_F32 ? pddr_run_impl<float>(p, pp, q, b, t, rho, gamma, n_iters, tol_kind, tol, first_loss_iter, ring, iters_done)

@@ -51,13 +51,19 @@ def taps_array(kernel) -> np.ndarray:
 
 
 class Plan:
-    def __init__(self, H: int, W: int, batch: int, dtype: torch.dtype, dev: torch.device, tune=None):
+    def __init__(self, H: int, W: int, batch: int, dtype: torch.dtype, dev: torch.device, tune=None, slab: bool = False):
+        """slab: a plan for the row-slab solvers that holds the multipliers of a tile range only (restrict_tiles)."""
         self.H, self.W, self.batch, self.dtype, self.dev = int(H), int(W), int(batch), dtype, dev
         self._h = C.c_void_p(0)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            L.check(L.lib().ddn_plan_create(C.byref(self._h), self.H, self.W, self.batch,
-                                            L.F64 if dtype == torch.float64 else L.F32, C.c_void_p(stream)))
+            dt = L.F64 if dtype == torch.float64 else L.F32
+            if slab:
+                if self.batch != 1 or tune:
+                    raise ValueError("a slab plan holds one image and takes no tuning")
+                L.check(L.lib().ddn_plan_create_slab(C.byref(self._h), self.H, self.W, dt, C.c_void_p(stream)))
+            else:
+                L.check(L.lib().ddn_plan_create(C.byref(self._h), self.H, self.W, self.batch, dt, C.c_void_p(stream)))
             if tune:
                 L.check(L.lib().ddn_plan_tune(self._h, int(tune.get("cols", 0)), int(tune.get("split", 0)),
                                               int(tune.get("col_threads", tune.get("row_threads", 0)))))
@@ -74,6 +80,11 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+    def restrict_tiles(self, tile_lo: int, n_tiles: int):
+        """Slab plans: allocate the multipliers of spectral tiles [tile_lo, tile_lo + n_tiles) (before set_kernel)."""
+        with torch.cuda.device(self.dev):
+            L.check(L.lib().ddn_slab_restrict(self._h, int(tile_lo), int(n_tiles)))
 
     def sync_stream(self):
         L.check(L.lib().ddn_plan_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))

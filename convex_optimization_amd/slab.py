@@ -151,7 +151,7 @@ class SlabSolver:
     """Plan, buffers and the two local stages of one slab-decomposed solve (fp32 or fp64)."""
 
     def __init__(self, kernel, image_shape: Tuple[int, int], t_resolvent: float, s_resolvent: float, dtype=torch.float32, device=None, group=None,
-                 n_spectra: int = 2, eig_arrays=None):
+                 n_spectra: int = 2, eig_arrays=None, local_multipliers: bool = True):
         from . import _lib as L
         from .plan import Plan, compute_device, real_dtype
         self.L = L
@@ -160,20 +160,25 @@ class SlabSolver:
         H, W = int(image_shape[0]), int(image_shape[1])
         self.dt = real_dtype(dtype)
         self.dev = compute_device(device)
-        self.plan = Plan(H, W, 1, self.dt, self.dev)
+        self.injected = eig_arrays is not None
+        # a rank keeps the multipliers of its own spectral tiles only; injected eigen arrays (the fp64 parity route)
+        # and local_multipliers=False take a plan with the whole plane, as a single-device solve has
+        self.local = bool(local_multipliers) and not self.injected
+        self.plan = Plan(H, W, 1, self.dt, self.dev, slab=self.local)
+        c, n = C.c_int(0), C.c_int(0)
+        L.check(L.lib().ddn_slab_layout(self.plan._h, C.byref(c), C.byref(n)))
+        self.lay = SlabLayout(H, W, c.value, n.value, self.rank, self.world)
+        if self.local:
+            self.plan.restrict_tiles(self.lay.tile_lo, self.lay.local_tiles)
         # eig_vals_mat = 1 + t^2 |eK|^2 + (t^2 + t s) |eD|^2   (multiplying_matrix.py:61-72 with D1 == D2)
         cK, cD = float(t_resolvent) ** 2, float(t_resolvent) ** 2 + float(t_resolvent) * float(s_resolvent)
-        if eig_arrays is not None:
+        if self.injected:
             # the reference's own eigen arrays of the WHOLE image, consumed bit for bit (fp64 parity)
             self.plan.set_eig(eig_arrays["K"], eig_arrays.get("D"))
             self.plan.set_resolvent(cK, cD, eig_arrays["M"])
         else:
             self.plan.set_kernel(kernel)
             self.plan.set_resolvent(cK, cD)
-        self.injected = eig_arrays is not None
-        c, n = C.c_int(0), C.c_int(0)
-        L.check(L.lib().ddn_slab_layout(self.plan._h, C.byref(c), C.byref(n)))
-        self.lay = SlabLayout(H, W, c.value, n.value, self.rank, self.world)
         self.xch = SlabExchange(self.lay, torch.complex128 if self.dt == torch.float64 else torch.complex64, self.dev, group, n_spectra)
         self._rec = torch.zeros((8,), dtype=torch.float64, device=self.dev)
         self._sums = torch.zeros((4,), dtype=torch.float64, device=self.dev)
@@ -283,7 +288,7 @@ def admm_solver_slab(b_rows: torch.Tensor, image_shape: Tuple[int, int], objecti
     from .plan import stage
     H, W = int(image_shape[0]), int(image_shape[1])
     sv = SlabSolver(kernel, (H, W), 1, 1, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
-                    eig_arrays=kwargs.get("eig_arrays"))
+                    eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True))
     try:
         lay, dev, dt = sv.lay, sv.dev, sv.dt
         if tuple(b_rows.shape) != (lay.rows, W):
@@ -360,7 +365,7 @@ def primal_dr_splitting_slab(problem: str, kernel, b_rows: torch.Tensor, image_s
     from .core.proximal_operators import prox_box
     H, W = int(image_shape[0]), int(image_shape[1])
     sv = SlabSolver(kernel, (H, W), t, t, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
-                    eig_arrays=kwargs.get("eig_arrays"))
+                    eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True))
     try:
         dev, dt = sv.dev, sv.dt
         bd = stage(b_rows, dev, dt)
@@ -396,7 +401,7 @@ def primal_dual_dr_splitting_slab(b_rows: torch.Tensor, kernel, image_shape: Tup
     from .core.proximal_operators import prox_box
     H, W = int(image_shape[0]), int(image_shape[1])
     sv = SlabSolver(kernel, (H, W), t, t, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
-                    eig_arrays=kwargs.get("eig_arrays"))
+                    eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True))
     try:
         lay, dev, dt = sv.lay, sv.dev, sv.dt
         bd = stage(b_rows, dev, dt)
@@ -435,7 +440,7 @@ def chambolle_pock_slab(b_rows: torch.Tensor, kernel, image_shape: Tuple[int, in
     from .plan import stage
     H, W = int(image_shape[0]), int(image_shape[1])
     sv = SlabSolver(kernel, (H, W), 1, 1, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
-                    n_spectra=1, eig_arrays=kwargs.get("eig_arrays"))
+                    n_spectra=1, eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True))
     try:
         lay, dev, dt = sv.lay, sv.dev, sv.dt
         b2 = b_rows.reshape(lay.rows, W)

@@ -239,6 +239,18 @@ int ddn_pddr_run(ddn_plan* p, void* p_dev, void* q_dev, const void* b_dev,
  * torch.distributed in this package).  Early stop: ddn_slab_begin / ddn_slab_stop_test below.  Injected eigen arrays
  * (ddn_plan_set_eig, ddn_plan_set_resolvent with M_dev: the fp64 parity route) are honoured. */
 int ddn_slab_layout(ddn_plan* p, int* tile_cols, int* n_tiles);
+/* A plan for the slab entries that holds the multipliers of the rank's own spectral tiles only (the reference keeps
+ * eig_vals_mat of the whole image on its one device, mm:67-72; a rank of the decomposition needs a 1/P share).
+ *   ddn_plan_create_slab   as ddn_plan_create with batch 1, but without half-spectra and whole-plane multipliers.
+ *   ddn_slab_restrict      (after ddn_slab_layout, before ddn_plan_set_kernel) allocates eK and the resolvent
+ *                          multiplier for tiles [tile_lo, tile_lo + n_tiles_local): H x C x n_tiles_local entries each.
+ * ddn_plan_set_kernel then evaluates the eigenvalues of those tiles straight from the taps (a double-precision sum over
+ * the taps per entry, rounded once: within one unit of the last place or two of the transform-built ones);
+ * ddn_plan_set_resolvent takes no injected array (DDN_E_UNSUPPORTED).  ddn_slab_cols / ddn_slab_cols_multiply accept
+ * tile ranges inside the restricted range only; every whole-plane entry (ddn_*_run, ddn_apply, ...) returns
+ * DDN_E_STATE on such a plan.  The column stage runs on the tile-generic kernels. */
+int ddn_plan_create_slab(ddn_plan** out, int H, int W, int dtype, void* stream);
+int ddn_slab_restrict(ddn_plan* p, int tile_lo, int n_tiles_local);
 /* Early stop of a slab solve (the reference's `break`: admm:152-154, pdr:159-161, pddr:119-121) without a host round
  * trip.  The stop flag lives in the plan; every ddn_slab_rows / ddn_slab_rows_cp launch skips its rows once it is set,
  * so the iterates stay as they were when the test fired (ADMM: pass sol_out_dev in every consuming launch, as

@@ -11,6 +11,16 @@ With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every ra
 independent image (weak scaling); there is no data-path collective, the per-iteration loss records
 are all-reduced over RCCL once per solver run, inside the timed region.
 
+Other workloads (--config):
+  batch1024rgb  BASELINE.json configs[3]: 1024 RGB images of 1024 x 1024 = 3072 independent planes, split over the
+                ranks with shard_range (strong scaling: the 3072 planes are fixed); every rank runs its planes in
+                chunks of --batch planes; the loss records of every `--check-every` iterations are summed over the
+                ranks with one small all-reduce (what a global stop decision needs), inside the timed region.
+  slab32768     BASELINE.json configs[4]: ONE 32768 x 32768 image, ADMM, rows split over the ranks, the column stage
+                on the rank's spectral tiles, two all-to-all exchanges per iteration, stop test (all-reduce of four
+                doubles) every iteration.  --size overrides the edge length (rehearsals).  --force-exchange makes a
+                one-rank run go through the collective calls as well.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -40,6 +50,17 @@ ROW_KERNEL = {"chambolle_pock": "k_wave_cp", "primal_dr_splitting": "k_wave_row<
               "admm_solver": "k_wave_row<admm>"}
 COL_KERNEL = {"chambolle_pock": "k_wave_col<multiplier>", "primal_dr_splitting": "k_wave_col<resolvent>",
               "primal_dual_dr_splitting": "k_wave_col<resolvent>", "admm_solver": "k_wave_col<resolvent>"}
+
+
+def kernel_name(table, solver, n, f64):
+    """Name of the kernel family that runs a line length n: register-resident for 4096 (fp32), several lines per
+    wavefront for 512-2048 (fp32), else the LDS kernels."""
+    base = table[solver]
+    if f64 or n not in (512, 1024, 2048, 4096):
+        return base.replace("k_wave_cp", "k_row_cp").replace("k_wave_row", "k_row").replace("k_wave_col", "k_col")
+    if n != 4096:
+        return base.replace("k_wave_cp", "k_wave_cpN").replace("k_wave_row<", "k_wave_rowN<").replace("k_wave_col<", "k_wave_colN<")
+    return base
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
@@ -59,6 +80,247 @@ def measured_traffic(lib_version, H, W, B):
     return best
 
 
+def _sync_all(dev, distributed):
+    torch.cuda.synchronize(dev)
+    if distributed:
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+
+def run_slab(args, dev, dt, rank, world, distributed, allreduce):
+    """One image of size x size, ADMM, rows split over the ranks (slab.py): W warm-up iterations, then K timed ones."""
+    import torch.distributed as dist
+    from convex_optimization_amd import _lib as L
+    from convex_optimization_amd import slab as S
+    from convex_optimization_amd.core.blur import create_motion_blur_kernel
+    H = W = args.size
+    K, Wm = args.steps, args.warmup
+    if H % world:
+        raise SystemExit(f"--size {H} is not a multiple of the {world} ranks")
+    rows = H // world
+    kern = create_motion_blur_kernel(15, 45)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    free0, total_mem = torch.cuda.mem_get_info(dev)
+    b = torch.rand((rows, W), device=dev, dtype=dt, generator=gen)   # rank-local rows of the blurred image
+    st = tuple(torch.clamp(torch.randn(sh, device=dev, dtype=dt, generator=gen), 0, 1) for sh in ((rows, W), (rows, W), (3, rows, W), (3, rows, W)))
+    sol = torch.zeros_like(b)
+    sv = S.SlabSolver(kern, (H, W), 1, 1, dtype=dt, device=dev, force_exchange=args.force_exchange, exchange_groups=args.exchange_groups)
+    ring = torch.zeros((max(K, Wm, 1), 8), dtype=torch.float64, device=dev)
+    t, rho, gamma, obj = 18.0, 0.001, 0.5, L.OBJ["l1"]
+    stages = {"rows": 0.0, "column_stage": 0.0, "stop_test": 0.0}
+    ev = []
+
+    def iterations(n, timed):
+        # steady-state iterations of admm_solver_slab (slab.py): column stage (exchange, column kernels, exchange),
+        # fused row kernel (consume + produce, look-ahead solution kept), stop test on the all-reduced loss sums
+        for c in range(1, n + 1):
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed and c % 5 == 0 else None
+            if marks: marks[0].record()
+            sv.column_stage()           # exchange, column kernels, exchange: pipelined over tile groups when there is an exchange
+            if marks: marks[1].record()
+            sv.rows(S.SOLVER_ADMM, st, b, t, rho, gamma, obj, True, True, sol=sol)
+            if marks: marks[2].record()
+            sv.stop_test(L.LOSS_PSNR, -1e300, c, 2, ring[c - 1])    # armed, never true
+            if marks:
+                marks[3].record()
+                ev.append(marks)
+            if c % args.check_every == 0:
+                assert sv.stopped_at() < 0
+
+    with torch.cuda.device(dev):
+        sv.plan.sync_stream()
+        sv.rows(S.SOLVER_ADMM, st, b, t, rho, gamma, obj, False, True)
+        iterations(max(Wm, 1), False)
+        _sync_all(dev, distributed)
+        t0 = time.perf_counter()
+        iterations(K, True)
+        _sync_all(dev, distributed)
+        t1 = time.perf_counter()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    for m in ev:
+        stages["column_stage"] += m[0].elapsed_time(m[1])
+        stages["rows"] += m[1].elapsed_time(m[2])
+        stages["stop_test"] += m[2].elapsed_time(m[3])
+    stages = {k: (v / len(ev) if ev else None) for k, v in stages.items()}
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        allreduce(el, dist.ReduceOp.MAX)
+    sec = float(el.item())
+    esz = 8 if dt == torch.float64 else 4
+    # bytes a rank sends per exchange: both half-spectra of its rows, minus the share it keeps
+    a2a_bytes = 2 * rows * (W // 2 + 1) * 2 * esz * (world - 1) / world
+    px = float(H) * W
+    out = {"metric": "Mpixel-iterations/sec, ADMM on one image split into row slabs", "value": px * K / sec / 1e6, "unit": "Mpixel-iterations/s",
+           "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": sec / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"one {H}x{W} image, ADMM (reference defaults), rows split over {world} rank(s), slab-decomposed 2-D transform, "
+                                  "two all-to-all exchanges and one 4-double all-reduce per iteration",
+                      "rows_per_rank": rows, "step": "one ADMM iteration of the whole image", "ddn_version": int(L.lib().ddn_version()),
+                      "exchange_forced": bool(args.force_exchange and world == 1), "backend": (dist.get_backend() if distributed else None),
+                      "all_to_all_bytes_sent_per_rank_per_exchange": a2a_bytes, "exchanges_per_iteration": 2, "exchange_tile_groups": sv.xch.groups},
+           "stage_ms": stages, "device_memory_in_use_gib": round((total_mem - free1) / 2**30, 2),
+           "iter_hbm_frac": WORDS_ITER["admm_solver"] * esz * px / world * K / sec / 1e9 / HBM_PEAK_GBS,
+           "final_loss": [float(v) for v in ring[K - 1, :4].cpu()], "solution_finite": bool(torch.isfinite(sol).all().item()),
+           "mse_per_iteration": [float(v) for v in ring[:K, 2].cpu()],
+           "roofline": {"bound": "hbm", "achieved": WORDS_ITER["admm_solver"] * esz * px / world * K / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": WORDS_ITER["admm_solver"] * esz * px / world * K / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "whole iteration (per GPU): the split-row kernels, the two-pass column kernels and the exchanges"}}
+    sv.close()
+    return out
+
+
+def run_batch(args, dev, dt, rank, world, distributed, allreduce):
+    """--planes independent planes of size x size split over the ranks; all four solvers; W warm-up, K timed iterations."""
+    import torch.distributed as dist
+    import convex_optimization_amd as pkg
+    from convex_optimization_amd import _lib as L
+    from convex_optimization_amd.plan import _ptr, Plan
+    from convex_optimization_amd.distributed import shard_range
+    from convex_optimization_amd.core.blur import create_motion_blur_kernel
+    H = W = args.size
+    K, Wm, ce = args.steps, args.warmup, max(1, args.check_every)
+    lo, hi = shard_range(args.planes, rank, world)
+    nloc = hi - lo
+    chunk = max(1, min(args.batch, nloc))
+    kern = create_motion_blur_kernel(15, 45)
+    lib = L.lib()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    solvers = [s for s in args.solvers.split(",") if s]
+    comm = torch.cuda.Stream(device=dev) if distributed else None
+    per_solver, total_time = {}, 0.0
+    esz = 8 if dt == torch.float64 else 4
+
+    def rnd(*shape):
+        return torch.rand(shape, device=dev, dtype=dt, generator=gen)
+
+    # the rank's planes, blurred, resident in HBM: chunks of `chunk` planes (the last one may be shorter)
+    chunks = []
+    for c0 in range(0, nloc, chunk):
+        n = min(chunk, nloc - c0)
+        pl = Plan(H, W, n, dt, dev)
+        chunks.append(pl.circular_convolve2d(kern, rnd(n, H, W)))
+        pl.close()
+    torch.cuda.synchronize(dev)
+
+    for name in solvers:
+        # one operator set (plan) per chunk size; iterate arrays of every chunk resident before timing
+        ops_by_n, states = {}, []
+        for b in chunks:
+            n = b.shape[0]
+            if n not in ops_by_n:
+                tr = {"chambolle_pock": (1, 1), "primal_dr_splitting": (2.0,), "primal_dual_dr_splitting": (3, 3), "admm_solver": (1, 1)}[name]
+                ops_by_n[n] = pkg.DeblurDenoiseOperators(kern, b[0], *tr, device=dev, batch=n, dtype=dt)
+            if name == "chambolle_pock":
+                states.append([rnd(n, H, W), rnd(n, H, W), rnd(3, n, H, W)])
+            elif name == "primal_dr_splitting":
+                states.append([b.clone(), torch.stack((b, b, b)).contiguous()])
+            elif name == "primal_dual_dr_splitting":
+                states.append([rnd(n, H, W), rnd(3, n, H, W)])
+            else:
+                states.append([torch.clamp(torch.randn((n, H, W), device=dev, dtype=dt, generator=gen), 0, 1) for _ in range(2)]
+                              + [torch.clamp(torch.randn((3, n, H, W), device=dev, dtype=dt, generator=gen), 0, 1) for _ in range(2)]
+                              + [torch.empty((n, H, W), device=dev, dtype=dt)])
+        done = torch.zeros((chunk,), dtype=torch.int32, device=dev)
+        rings = [torch.zeros((ce, b.shape[0], 8), dtype=torch.float64, device=dev) for b in chunks]
+        pending = []
+
+        def segment(ci, n_it):
+            b, st, ring = chunks[ci], states[ci], rings[ci]
+            h = ops_by_n[b.shape[0]].plan._h
+            if name == "chambolle_pock":
+                L.check(lib.ddn_cp_run(h, _ptr(st[0]), _ptr(st[1]), _ptr(st[2]), _ptr(b), 0.4, 0.7, 0.01, 0, n_it, _ptr(ring)))
+            elif name == "primal_dr_splitting":
+                L.check(lib.ddn_pdr_run(h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 2.0, 0.1, 0.049, 0, n_it, L.LOSS_MSE, -1.0, 3, _ptr(ring), _ptr(done)))
+            elif name == "primal_dual_dr_splitting":
+                L.check(lib.ddn_pddr_run(h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 3.0, 0.4, 0.03, n_it, L.LOSS_L2, -1.0, 2, _ptr(ring), _ptr(done)))
+            else:
+                L.check(lib.ddn_admm_run(h, _ptr(st[0]), _ptr(st[1]), _ptr(st[2]), _ptr(st[3]), _ptr(b), 18.0, 0.001, 0.5, 0, n_it,
+                                         L.LOSS_PSNR, -1.0, 2, _ptr(ring), _ptr(done), _ptr(st[4])))
+
+        def sweep(n_it):
+            # n_it iterations of every local plane, `ce` at a time; after each group of `ce` iterations the loss records,
+            # summed over the rank's planes, join an all-reduce over the ranks on a side stream
+            it = 0
+            while it < n_it:
+                m = min(ce, n_it - it)
+                acc = torch.zeros((ce, 8), dtype=torch.float64, device=dev)
+                for ci in range(len(chunks)):
+                    segment(ci, m)
+                    acc[:m] += rings[ci][:m].sum(dim=1)
+                if distributed:
+                    if dist.get_backend() == "nccl":
+                        comm.wait_stream(torch.cuda.current_stream(dev))
+                        with torch.cuda.stream(comm):
+                            pending.append((acc, dist.all_reduce(acc, op=dist.ReduceOp.SUM, async_op=True)))
+                    else:
+                        allreduce(acc, dist.ReduceOp.SUM)
+                it += m
+            for acc, work in pending:
+                work.wait()
+            pending.clear()
+
+        for o in ops_by_n.values():
+            o.plan.sync_stream()
+        if Wm > 0:
+            sweep(Wm)
+        _sync_all(dev, distributed)
+        for o in ops_by_n.values():
+            o.plan.enable_timing(0 if args.no_kernel_timing else 5)
+        t0 = time.perf_counter()
+        sweep(K)
+        _sync_all(dev, distributed)
+        t1 = time.perf_counter()
+        tms = []
+        for o in ops_by_n.values():
+            o.plan.enable_timing(False)
+            tms.append((o.plan.batch, o.plan.last_timing()))
+        el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+        if distributed:
+            allreduce(el, dist.ReduceOp.MAX)
+        sec = float(el.item())
+        total_time += sec
+        px_all = float(args.planes) * H * W
+        nb, tm = max(tms, key=lambda x: x[0])     # kernel durations of the full-size chunk
+        pxc = float(nb) * H * W
+        per_solver[name] = {"mpix_it_per_s": px_all * K / sec / 1e6, "ms_per_iter": sec / K * 1e3,
+                            "iter_hbm_frac": WORDS_ITER[name] * esz * (px_all / world) * K / sec / 1e9 / HBM_PEAK_GBS,
+                            "row_kernel_ms": tm["row_ms"], "col_kernel_ms": tm["col_ms"], "planes_per_launch": nb,
+                            "row_kernel_gbs": (WORDS_ROW[name] * esz * pxc / (tm["row_ms"] * 1e-3) / 1e9) if tm["row_ms"] > 0 else None,
+                            "col_kernel_gbs": (WORDS_COL[name] * esz * pxc / (tm["col_ms"] * 1e-3) / 1e9) if tm["col_ms"] > 0 else None}
+        for o in ops_by_n.values():
+            o.close()
+        del states, rings
+        torch.cuda.empty_cache()
+
+    px_all = float(args.planes) * H * W
+    nsol = len(solvers)
+    value = px_all * K * nsol / total_time / 1e6
+    kernels = {}
+    for sname, ps in per_solver.items():
+        lpi = 2 if sname == "chambolle_pock" else 1
+        for kind, words, ms, gbs in (("row", WORDS_ROW[sname], ps["row_kernel_ms"], ps["row_kernel_gbs"]), ("col", WORDS_COL[sname], ps["col_kernel_ms"], ps["col_kernel_gbs"])):
+            if ms and ms > 0:
+                kernels[f"{kind} kernel of {sname}"] = {"ms": ms, "launches_per_iteration_per_chunk": lpi, "algorithmic_bytes": words * esz * ps["planes_per_launch"] * H * W,
+                                                        "achieved_gbs": gbs, "frac": gbs / HBM_PEAK_GBS, "share_ms": ms * lpi}
+    roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": None}
+    if kernels:
+        dom = max(kernels, key=lambda k: kernels[k]["share_ms"])
+        roof.update({"achieved": kernels[dom]["achieved_gbs"], "frac": kernels[dom]["frac"], "kernel": dom,
+                     "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"], "kernel_ms": kernels[dom]["ms"]})
+    roof["kernels"] = kernels
+    roof["whole_iteration_frac"] = {s_: per_solver[s_]["iter_hbm_frac"] for s_ in per_solver}
+    return {"metric": "Mpixel-iterations/sec per solver, batch of independent planes", "value": value, "unit": "Mpixel-iterations/s", "n_gpus": world,
+            "steps": K, "warmup": Wm, "ms_per_step": total_time / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.planes} independent {H}x{W} planes ({args.planes // 3} RGB images), 15-tap motion blur, all four solvers, reference defaults; "
+                                   f"planes split over the ranks (shard_range), {chunk} planes per launch, loss records all-reduced every {ce} iterations",
+                       "planes_per_gpu": nloc, "solvers": solvers, "step": "one iteration of each solver on every plane", "ddn_version": int(lib.ddn_version())},
+            "per_solver": per_solver, "roofline": roof}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,14 +333,28 @@ def main():
     ap.add_argument("--solvers", default="chambolle_pock,primal_dr_splitting,primal_dual_dr_splitting,admm_solver")
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--split", type=int, default=0)
-    ap.add_argument("--row-threads", type=int, default=0)
+    ap.add_argument("--col-threads", "--row-threads", dest="col_threads", type=int, default=0, help="threads per workgroup of the tile-generic column kernels")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP events (roofline fields become null)")
+    ap.add_argument("--config", default="image4096", choices=["image4096", "batch1024rgb", "slab32768"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--check-every", type=int, default=10)
+    ap.add_argument("--planes", type=int, default=3072, help="batch1024rgb: planes in all (1024 RGB images)")
+    ap.add_argument("--force-exchange", action="store_true")
+    ap.add_argument("--exchange-groups", type=int, default=0, help="slab32768: tile groups of the pipelined exchange (0 = automatic, 1 = one exchange)")
     args = ap.parse_args()
+    if args.config == "batch1024rgb" and "--size" not in sys.argv:
+        args.size = 1024
+    if args.config == "batch1024rgb" and "--batch" not in sys.argv:
+        args.batch = 256
+    if args.config == "slab32768" and "--size" not in sys.argv:
+        args.size = 32768
+    if args.config == "slab32768" and "--steps" not in sys.argv:
+        args.steps = 20
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or (args.force_exchange and args.config == "slab32768")
     # one rank per GPU; the modulo only matters in a rehearsal of the multi-rank path on a box with fewer GPUs than
     # ranks (DDN_BENCH_BACKEND=gloo: RCCL itself refuses two ranks on one device)
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
@@ -87,6 +363,11 @@ def main():
     if distributed:
         import torch.distributed as dist
         backend = os.environ.get("DDN_BENCH_BACKEND", "nccl")
+        if world == 1:      # a one-rank group of its own (--force-exchange): no launcher has set the rendezvous
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -111,9 +392,25 @@ def main():
     H = W = args.size
     B = args.batch
     K, Wm = args.steps, args.warmup
-    dt = torch.float32
+    dt = torch.float64 if args.dtype == "f64" else torch.float32
+    if args.config == "slab32768":
+        out = run_slab(args, dev, dt, rank, world, distributed, allreduce if distributed else None)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if distributed:
+            dist.destroy_process_group()
+        return
+    if args.config == "batch1024rgb":
+        out = run_batch(args, dev, dt, rank, world, distributed, allreduce if distributed else None)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if distributed:
+            dist.destroy_process_group()
+        return
+    f64 = dt == torch.float64
+    esz = 8.0 if f64 else 4.0
     kern = create_motion_blur_kernel(15, 45)
-    tune = {"cols": args.cols, "split": args.split, "row_threads": args.row_threads}
+    tune = {"cols": args.cols, "split": args.split, "col_threads": args.col_threads}
 
     # synthetic input, generated rank-locally on the device, resident in HBM before timing
     gen = torch.Generator(device=dev)
@@ -161,8 +458,8 @@ def main():
                 L.check(lib.ddn_pddr_run(ops.plan._h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 3.0, 0.4, 0.03, n, L.LOSS_L2, -1.0, 2, _ptr(ring), _ptr(done)))
         elif name == "admm_solver":
             ops = pkg.DeblurDenoiseOperators(kern, b[0], 1, 1, device=dev, batch=B, dtype=dt, tune=tune)
-            st = [torch.clamp(torch.randn((B, H, W), device=dev, generator=gen), 0, 1), torch.clamp(torch.randn((B, H, W), device=dev, generator=gen), 0, 1),
-                  torch.clamp(torch.randn((3, B, H, W), device=dev, generator=gen), 0, 1), torch.clamp(torch.randn((3, B, H, W), device=dev, generator=gen), 0, 1),
+            st = [torch.clamp(torch.randn((B, H, W), device=dev, dtype=dt, generator=gen), 0, 1), torch.clamp(torch.randn((B, H, W), device=dev, dtype=dt, generator=gen), 0, 1),
+                  torch.clamp(torch.randn((3, B, H, W), device=dev, dtype=dt, generator=gen), 0, 1), torch.clamp(torch.randn((3, B, H, W), device=dev, dtype=dt, generator=gen), 0, 1),
                   torch.empty((B, H, W), device=dev, dtype=dt)]
             def run(n, ring, st=st, ops=ops):
                 L.check(lib.ddn_admm_run(ops.plan._h, _ptr(st[0]), _ptr(st[1]), _ptr(st[2]), _ptr(st[3]), _ptr(b), 18.0, 0.001, 0.5, 0, n,
@@ -199,10 +496,10 @@ def main():
         per_solver[name] = {
             "mpix_it_per_s": world * px * K / sec / 1e6,
             "ms_per_iter": sec / K * 1e3,
-            "iter_hbm_frac": WORDS_ITER[name] * 4.0 * px * K / sec / 1e9 / HBM_PEAK_GBS,
+            "iter_hbm_frac": WORDS_ITER[name] * esz * px * K / sec / 1e9 / HBM_PEAK_GBS,
             "row_kernel_ms": row_ms, "col_kernel_ms": tm["col_ms"], "n_row": tm["n_row"], "n_col": tm["n_col"],
-            "row_kernel_gbs": (WORDS_ROW[name] * 4.0 * px / (row_ms * 1e-3) / 1e9) if row_ms > 0 else None,
-            "col_kernel_gbs": (WORDS_COL[name] * 4.0 * px / (tm["col_ms"] * 1e-3) / 1e9) if tm["col_ms"] > 0 else None,
+            "row_kernel_gbs": (WORDS_ROW[name] * esz * px / (row_ms * 1e-3) / 1e9) if row_ms > 0 else None,
+            "col_kernel_gbs": (WORDS_COL[name] * esz * px / (tm["col_ms"] * 1e-3) / 1e9) if tm["col_ms"] > 0 else None,
             "final_loss": [float(v) for v in ring[K - 1, 0, :4].cpu()],
         }
         ops.close()
@@ -219,14 +516,14 @@ def main():
     kernels = {}
     for sname, ps in per_solver.items():
         lpi = 2 if sname == "chambolle_pock" else 1
-        for kind, kname, words, ms in (("row", ROW_KERNEL[sname], WORDS_ROW[sname], ps["row_kernel_ms"]),
-                                       ("col", COL_KERNEL[sname], WORDS_COL[sname], ps["col_kernel_ms"])):
+        for kind, kname, words, ms in (("row", kernel_name(ROW_KERNEL, sname, W, f64), WORDS_ROW[sname], ps["row_kernel_ms"]),
+                                       ("col", kernel_name(COL_KERNEL, sname, H, f64), WORDS_COL[sname], ps["col_kernel_ms"])):
             if not ms or ms <= 0:
                 continue
-            e = kernels.setdefault(kname, {"ms_per_step": 0.0, "launches_per_step": 0, "algorithmic_bytes": words * 4.0 * px, "_bytes": 0.0})
+            e = kernels.setdefault(kname, {"ms_per_step": 0.0, "launches_per_step": 0, "algorithmic_bytes": words * esz * px, "_bytes": 0.0})
             e["ms_per_step"] += ms * lpi
             e["launches_per_step"] += lpi
-            e["_bytes"] += words * 4.0 * px * lpi
+            e["_bytes"] += words * esz * px * lpi
     for kname, e in kernels.items():
         e["ms"] = e["ms_per_step"] / e["launches_per_step"]
         e["achieved_gbs"] = e.pop("_bytes") / (e["ms_per_step"] * 1e-3) / 1e9
@@ -246,8 +543,8 @@ def main():
         "metric": "Mpixel-iterations/sec per solver at 4096^2 + % HBM roofline",
         "value": value, "unit": "Mpixel-iterations/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": total_time / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{H}x{W} grayscale motion-blur (15 taps @45deg) deconvolution, fp32, all four solvers, reference default parameters"
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{H}x{W} grayscale motion-blur (15 taps @45deg) deconvolution, {args.dtype}, all four solvers, reference default parameters"
                                " (Chambolle-Pock's defaults t=0.4, s=0.7 are outside its stable range; its iterates are pinned against the reference for N <= 20 only)",
                    "images_per_gpu": B, "solvers": solvers, "step": "one iteration of each solver", "ddn_version": lib_version},
         "per_solver": per_solver,

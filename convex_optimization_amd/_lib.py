@@ -61,6 +61,7 @@ def lib():
         "ddn_plan_enable_timing": [vp, i],
         "ddn_slab_layout": [vp, C.POINTER(i), C.POINTER(i)],
         "ddn_plan_create_slab": [C.POINTER(vp), i, i, i, vp],
+        "ddn_slab_cols_part": [vp, vp, i, i, i, i, i, i],
         "ddn_slab_restrict": [vp, i, i],
         "ddn_slab_rows": [vp, i, i, vp, vp, vp, vp, vp, vp, d, d, d, i, i, i, vp, i],
         "ddn_slab_cols": [vp, vp, i, i, i],
@@ -93,4 +94,4 @@ EXPORTED = ["ddn_version", "ddn_last_error", "ddn_plan_create", "ddn_plan_destro
             "ddn_plan_set_kernel", "ddn_plan_set_eig", "ddn_plan_set_resolvent", "ddn_plan_set_ssim", "ddn_plan_get_eigK", "ddn_apply",
             "ddn_apply_multiplier", "ddn_circular_convolve2d", "ddn_prox", "ddn_reduce", "ddn_reduce_static", "ddn_ssim", "ddn_apply_x_trans", "ddn_cp_run", "ddn_admm_run",
             "ddn_pdr_run", "ddn_pddr_run", "ddn_plan_last_timing", "ddn_plan_enable_timing", "ddn_plan_debug_stamps",
-            "ddn_slab_layout", "ddn_plan_create_slab", "ddn_slab_restrict", "ddn_slab_rows", "ddn_slab_cols", "ddn_slab_loss", "ddn_slab_begin", "ddn_slab_loss_sums", "ddn_slab_stop_test", "ddn_slab_iters_done", "ddn_slab_rows_cp", "ddn_slab_cols_multiply"]
+            "ddn_slab_layout", "ddn_slab_cols_part", "ddn_plan_create_slab", "ddn_slab_restrict", "ddn_slab_rows", "ddn_slab_cols", "ddn_slab_loss", "ddn_slab_begin", "ddn_slab_loss_sums", "ddn_slab_stop_test", "ddn_slab_iters_done", "ddn_slab_rows_cp", "ddn_slab_cols_multiply"]

@@ -1331,9 +1331,12 @@ int slab_rows_impl(ddn_plan* p, int solver, int rows, void* spec, void* s0, void
 // Column stage on tiles [tile_lo, tile_lo + ntiles) of the image's half-spectra: MODE COL_RES2 (the
 // resolvent solvers; spec holds both spectra) or COL_MUL (Chambolle-Pock: one spectrum times eK or conj(eK)).
 template <typename T, int MODE>
-int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles, int conj_mult, int nblocks) {
+int slab_cols_impl(ddn_plan* p, void* spec_all, int tile_lo_all, int ntiles_all, int conj_mult, int nblocks, int first, int count) {
     if (!p->have_K || (MODE == COL_RES2 && !p->have_G)) return fail(DDN_E_STATE, "slab_cols: operators not set");
-    if (ntiles == 0) return DDN_OK;
+    // the buffer holds ntiles_all tiles from tile_lo_all on; this call works on `count` of them from the first-th on
+    if (first < 0 || count < 0 || first + count > ntiles_all) return fail(DDN_E_ARG, "slab_cols: part outside the buffer's tiles");
+    if (count == 0) return DDN_OK;
+    const int tile_lo = tile_lo_all + first, ntiles = count;
     if (p->restricted && (tile_lo < p->slab_lo || tile_lo + ntiles > p->slab_lo + p->slab_n))
         return fail(DDN_E_ARG, "slab_cols: tiles outside the range given to ddn_slab_restrict");
     constexpr int NS = MODE == COL_RES2 ? 2 : 1;
@@ -1345,18 +1348,19 @@ int slab_cols_impl(ddn_plan* p, void* spec, int tile_lo, int ntiles, int conj_mu
     // rank i by i * (ntiles * NS - 1) * rows rows.
     int pitch = 0, sh = 0;
     long long extra_rows = 0;
-    size_t s1_off = (size_t)ntiles * ((size_t)p->H << p->cs);
+    size_t s1_off = (size_t)ntiles_all * ((size_t)p->H << p->cs);
     if (nblocks >= 1) {
         if (p->H % nblocks) return fail(DDN_E_ARG, "slab_cols: H is not a multiple of the number of row blocks");
         const int rows = p->H / nblocks;
         pitch = NS * rows;
         s1_off = (size_t)rows * C;
-        extra_rows = nblocks > 1 ? (long long)rows * (ntiles * NS - 1) : 0;
+        extra_rows = nblocks > 1 ? (long long)rows * (ntiles_all * NS - 1) : 0;
         if (extra_rows) {
             if (rows & (rows - 1)) return fail(DDN_E_UNSUPPORTED, "slab_cols: rows per block must be a power of two");
             while ((1 << sh) < rows) ++sh;
         }
     }
+    void* const spec = (cx<T>*)spec_all + (size_t)first * ((size_t)(pitch ? pitch : p->H) << p->cs);   // tile `first` of the buffer
     if constexpr (sizeof(T) == 4) {
         // H = 4096 / 512-2048: the register-resident column kernels, pointed at the local columns (their
         // multipliers are column-major, so a column range is a pointer offset; column W/2 stays in its tile)
@@ -1873,24 +1877,27 @@ int ddn_slab_rows(ddn_plan* p, int solver, int rows, void* spec_rows, void* s0, 
     return slab_rows_impl<double>(p, solver, rows, spec_rows, s0, s1, s2, s3, b, t, rho, gamma, objective, consume, produce, sol, sol_only);
 }
 
-int ddn_slab_cols(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local, int n_row_blocks) {
+int ddn_slab_cols_part(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local, int n_row_blocks, int mode, int first, int count) {
     if (!p || (!spec_cols && n_tiles_local > 0)) return fail(DDN_E_ARG, "slab_cols: null argument");
     if (p->batch != 1) return fail(DDN_E_ARG, "slab_cols: the plan must hold one image");
     if (tile_lo < 0 || n_tiles_local < 0 || tile_lo + n_tiles_local > p->ntile) return fail(DDN_E_ARG, "slab_cols: bad tile range");
     if (p->tile_pad_rows) return fail(DDN_E_UNSUPPORTED, "slab_cols: padded tiles are not supported");
     if (n_row_blocks < 0) return fail(DDN_E_ARG, "slab_cols: bad number of row blocks");
-    if (p->dtype == DDN_F32) return slab_cols_impl<float, COL_RES2>(p, spec_cols, tile_lo, n_tiles_local, 0, n_row_blocks);
-    return slab_cols_impl<double, COL_RES2>(p, spec_cols, tile_lo, n_tiles_local, 0, n_row_blocks);
+    if (mode < 0 || mode > 2) return fail(DDN_E_ARG, "slab_cols: mode is 0 (resolvent), 1 (times eK) or 2 (times conj eK)");
+    if (mode == 0) {
+        if (p->dtype == DDN_F32) return slab_cols_impl<float, COL_RES2>(p, spec_cols, tile_lo, n_tiles_local, 0, n_row_blocks, first, count);
+        return slab_cols_impl<double, COL_RES2>(p, spec_cols, tile_lo, n_tiles_local, 0, n_row_blocks, first, count);
+    }
+    if (p->dtype == DDN_F32) return slab_cols_impl<float, COL_MUL>(p, spec_cols, tile_lo, n_tiles_local, mode == 2 ? 1 : 0, n_row_blocks, first, count);
+    return slab_cols_impl<double, COL_MUL>(p, spec_cols, tile_lo, n_tiles_local, mode == 2 ? 1 : 0, n_row_blocks, first, count);
+}
+
+int ddn_slab_cols(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local, int n_row_blocks) {
+    return ddn_slab_cols_part(p, spec_cols, tile_lo, n_tiles_local, n_row_blocks, 0, 0, n_tiles_local);
 }
 
 int ddn_slab_cols_multiply(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local, int conj, int n_row_blocks) {
-    if (!p || (!spec_cols && n_tiles_local > 0)) return fail(DDN_E_ARG, "slab_cols_multiply: null argument");
-    if (p->batch != 1) return fail(DDN_E_ARG, "slab_cols_multiply: the plan must hold one image");
-    if (tile_lo < 0 || n_tiles_local < 0 || tile_lo + n_tiles_local > p->ntile) return fail(DDN_E_ARG, "slab_cols_multiply: bad tile range");
-    if (p->tile_pad_rows) return fail(DDN_E_UNSUPPORTED, "slab_cols_multiply: padded tiles are not supported");
-    if (n_row_blocks < 0) return fail(DDN_E_ARG, "slab_cols_multiply: bad number of row blocks");
-    if (p->dtype == DDN_F32) return slab_cols_impl<float, COL_MUL>(p, spec_cols, tile_lo, n_tiles_local, conj ? 1 : 0, n_row_blocks);
-    return slab_cols_impl<double, COL_MUL>(p, spec_cols, tile_lo, n_tiles_local, conj ? 1 : 0, n_row_blocks);
+    return ddn_slab_cols_part(p, spec_cols, tile_lo, n_tiles_local, n_row_blocks, conj ? 2 : 1, 0, n_tiles_local);
 }
 
 int ddn_slab_rows_cp(ddn_plan* p, int rows, void* spec_rows, void* spec_aux, void* x, void* z, void* y, const void* b, double t, double s, double gamma,

@@ -18,6 +18,11 @@ The column kernels address the per-source row blocks of the column side directly
 power of two), so neither side repacks anything; for other row counts one strided device copy on the
 receiving side builds [2][local tiles][H][C] instead.
 
+Tile groups: with `exchange_groups` = G > 1 (the default picks G so that a message between two ranks stays below
+256 MiB, and at least 4 when there is an exchange at all) the tiles of every rank are cut into G groups and the column
+stage becomes a pipeline: inbound exchange of group g + 1, column kernels of group g and outbound exchange of group
+g - 1 are in flight together (the collectives on RCCL's stream, ordered against the plan's stream by events).
+
 Loss records add up over ranks: every rank finalises the sums of its own rows, the sums of |d| and
 d^2 are all-reduced, and l2 / mse / psnr are recomputed from the totals.  Without a loss_function that
 happens once per solve.  With loss_function = l1_loss / l2_loss / mse / psnr of this package (and tol) the
@@ -69,14 +74,18 @@ class SlabExchange:
     rank spec_cols IS spec_rows.  Otherwise spec_cols is [spectra][local tiles][H][C] and one strided device
     copy on the receiving side puts every source's rows at their global row index (n_row_blocks = 0)."""
 
-    def __init__(self, lay: SlabLayout, complex_dtype: torch.dtype, device, group=None, n_spectra: int = 2):
+    def __init__(self, lay: SlabLayout, complex_dtype: torch.dtype, device, group=None, n_spectra: int = 2, force_exchange: bool = False,
+                 exchange_groups: int = 0):
+        """force_exchange: with one rank the all-to-all is an identity and is skipped; True makes it happen anyway (the
+        collective then runs with a one-rank group: the call shape of the multi-rank exchange, on one device)."""
         self.lay, self.group, self.ns = lay, group, int(n_spectra)
         ns = self.ns
+        self.exchange = lay.world > 1 or (bool(force_exchange) and dist.is_available() and dist.is_initialized())
         self.blocked = lay.world == 1 or (lay.rows & (lay.rows - 1)) == 0
         self.n_row_blocks = lay.world if self.blocked else 0
         self.spec_rows = torch.zeros((lay.n_tiles, ns, lay.rows, lay.C), dtype=complex_dtype, device=device)
         stage = None
-        if lay.world > 1:
+        if self.exchange:
             stage = torch.zeros((lay.world, lay.local_tiles, ns, lay.rows, lay.C), dtype=complex_dtype, device=device)
         if self.blocked:
             self.spec_cols = stage if stage is not None else self.spec_rows.unsqueeze(0)
@@ -87,6 +96,78 @@ class SlabExchange:
         per_tile = ns * lay.rows * lay.C * 2  # real numbers per tile of the row-side layout
         self._row_splits = [(hi - lo) * per_tile for lo, hi in lay.tile_spans]
         self._col_splits = [lay.local_tiles * per_tile] * lay.world
+        # tile groups of the pipelined column stage (blocked layout only: the other one repacks whole buffers)
+        self.groups = 1
+        if self.exchange and self.blocked:
+            esz = 16 if complex_dtype == torch.complex128 else 8
+            biggest = max(hi - lo for lo, hi in lay.tile_spans) * ns * lay.rows * lay.C * esz   # bytes between two ranks per exchange
+            want = int(exchange_groups) if exchange_groups else max(4, -(-biggest // (256 << 20)))
+            self.groups = max(1, min(want, min(hi - lo for lo, hi in lay.tile_spans) or 1))
+        self._comm = None
+
+    def group_range(self, n_tiles: int, g: int) -> Tuple[int, int]:
+        """[a, b) of group g among n_tiles tiles: the same rule on the sending and the receiving side."""
+        c = -(-n_tiles // self.groups)
+        return min(g * c, n_tiles), min((g + 1) * c, n_tiles)
+
+    def _a2a_group(self, g: int, to_cols: bool):
+        """Exchange of tile group g: rows -> columns (to_cols) or back.  Returns a work handle to wait on (or None)."""
+        lay = self.lay
+        a, b = self.group_range(lay.local_tiles, g)
+        col_side = [self.spec_cols[src, a:b] for src in range(lay.world)]
+        row_side = []
+        for lo, hi in lay.tile_spans:
+            ra, rb = self.group_range(hi - lo, g)
+            row_side.append(self.spec_rows[lo + ra:lo + rb])
+        out_list, in_list = (col_side, row_side) if to_cols else (row_side, col_side)
+        out_list = [torch.view_as_real(t) for t in out_list]
+        in_list = [torch.view_as_real(t) for t in in_list]
+        if dist.get_backend(self.group) == "nccl":
+            return dist.all_to_all(out_list, in_list, group=self.group, async_op=True)
+        # gloo (tests): one host-staged all_to_all_single with the pieces packed back to back
+        inp = torch.cat([t.reshape(-1) for t in in_list]).cpu()
+        out = torch.empty(sum(t.numel() for t in out_list), dtype=inp.dtype)
+        dist.all_to_all_single(out, inp, [t.numel() for t in out_list], [t.numel() for t in in_list], group=self.group)
+        o = 0
+        for t in out_list:
+            t.copy_(out[o:o + t.numel()].view(t.shape))
+            o += t.numel()
+        return None
+
+    def pipelined(self, col_fn):
+        """The whole column stage in tile groups: col_fn(first, count) launches the column kernels of the local tiles
+        [first, first + count) on the current stream.  Inbound exchanges run two groups ahead of the kernels."""
+        dev = self.spec_rows.device
+        main = torch.cuda.current_stream(dev)
+        nccl = dist.get_backend(self.group) == "nccl"
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=dev)
+        comm = self._comm
+
+        def issue(g, to_cols):
+            if not nccl:
+                return self._a2a_group(g, to_cols)
+            ev = main.record_event()
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev)
+                return self._a2a_group(g, to_cols)
+
+        G = self.groups
+        inbound = {g: issue(g, True) for g in range(min(2, G))}
+        outbound = []
+        for g in range(G):
+            w = inbound.pop(g)
+            if w is not None:
+                w.wait()                      # the current stream waits for group g to have arrived
+            a, b = self.group_range(self.lay.local_tiles, g)
+            if b > a:
+                col_fn(a, b - a)
+            outbound.append(issue(g, False))
+            if g + 2 < G:
+                inbound[g + 2] = issue(g + 2, True)
+        for w in outbound:
+            if w is not None:
+                w.wait()
 
     def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], in_splits: Sequence[int]):
         o = torch.view_as_real(out).reshape(-1)
@@ -105,7 +186,7 @@ class SlabExchange:
 
     def rows_to_cols(self):
         """Every rank's rows of my tiles -> spec_cols (all H rows of the local tiles)."""
-        if self.lay.world == 1:
+        if not self.exchange:
             return  # spec_cols is spec_rows
         if self.blocked:
             self._a2a(self.spec_cols, self.spec_rows, self._col_splits, self._row_splits)
@@ -115,7 +196,7 @@ class SlabExchange:
 
     def cols_to_rows(self):
         """spec_cols -> my rows of every tile in spec_rows."""
-        if self.lay.world == 1:
+        if not self.exchange:
             return
         if self.blocked:
             self._a2a(self.spec_rows, self.spec_cols, self._row_splits, self._col_splits)
@@ -151,7 +232,7 @@ class SlabSolver:
     """Plan, buffers and the two local stages of one slab-decomposed solve (fp32 or fp64)."""
 
     def __init__(self, kernel, image_shape: Tuple[int, int], t_resolvent: float, s_resolvent: float, dtype=torch.float32, device=None, group=None,
-                 n_spectra: int = 2, eig_arrays=None, local_multipliers: bool = True):
+                 n_spectra: int = 2, eig_arrays=None, local_multipliers: bool = True, force_exchange: bool = False, exchange_groups: int = 0):
         from . import _lib as L
         from .plan import Plan, compute_device, real_dtype
         self.L = L
@@ -179,7 +260,7 @@ class SlabSolver:
         else:
             self.plan.set_kernel(kernel)
             self.plan.set_resolvent(cK, cD)
-        self.xch = SlabExchange(self.lay, torch.complex128 if self.dt == torch.float64 else torch.complex64, self.dev, group, n_spectra)
+        self.xch = SlabExchange(self.lay, torch.complex128 if self.dt == torch.float64 else torch.complex64, self.dev, group, n_spectra, force_exchange, exchange_groups)
         self._rec = torch.zeros((8,), dtype=torch.float64, device=self.dev)
         self._sums = torch.zeros((4,), dtype=torch.float64, device=self.dev)
         self._done = torch.full((1,), -1, dtype=torch.int32, device=self.dev)
@@ -198,6 +279,10 @@ class SlabSolver:
     def column_stage(self):
         """rows -> columns all-to-all, local column stage, columns -> rows all-to-all."""
         from .plan import _ptr
+        if self.xch.groups > 1:
+            self.xch.pipelined(lambda first, count: self.L.check(self.L.lib().ddn_slab_cols_part(
+                self.plan._h, _ptr(self.xch.spec_cols), self.lay.tile_lo, self.lay.local_tiles, self.xch.n_row_blocks, 0, first, count)))
+            return
         self.xch.rows_to_cols()
         self.L.check(self.L.lib().ddn_slab_cols(self.plan._h, _ptr(self.xch.spec_cols), self.lay.tile_lo, self.lay.local_tiles, self.xch.n_row_blocks))
         self.xch.cols_to_rows()
@@ -213,6 +298,10 @@ class SlabSolver:
     def column_multiply(self, conj: bool):
         """rows -> columns all-to-all, spectrum times eK (or its conjugate) on the local tiles, all-to-all back."""
         from .plan import _ptr
+        if self.xch.groups > 1:
+            self.xch.pipelined(lambda first, count: self.L.check(self.L.lib().ddn_slab_cols_part(
+                self.plan._h, _ptr(self.xch.spec_cols), self.lay.tile_lo, self.lay.local_tiles, self.xch.n_row_blocks, 2 if conj else 1, first, count)))
+            return
         self.xch.rows_to_cols()
         self.L.check(self.L.lib().ddn_slab_cols_multiply(self.plan._h, _ptr(self.xch.spec_cols), self.lay.tile_lo, self.lay.local_tiles, int(conj),
                                                          self.xch.n_row_blocks))
@@ -223,7 +312,7 @@ class SlabSolver:
         `loss < tol` on the device: local sums -> all-reduce (SUM) of four doubles -> every rank decides alike."""
         from .plan import _ptr
         self.L.check(self.L.lib().ddn_slab_loss_sums(self.plan._h, self.lay.rows, _ptr(self._sums)))
-        if self.world > 1:
+        if self.world > 1 or self.xch.exchange:
             if dist.get_backend(self.group) == "gloo" and self._sums.is_cuda:
                 h = self._sums.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -288,7 +377,7 @@ def admm_solver_slab(b_rows: torch.Tensor, image_shape: Tuple[int, int], objecti
     from .plan import stage
     H, W = int(image_shape[0]), int(image_shape[1])
     sv = SlabSolver(kernel, (H, W), 1, 1, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
-                    eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True))
+                    eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True), force_exchange=kwargs.get("force_exchange", False), exchange_groups=kwargs.get("exchange_groups", 0))
     try:
         lay, dev, dt = sv.lay, sv.dev, sv.dt
         if tuple(b_rows.shape) != (lay.rows, W):
@@ -365,7 +454,7 @@ def primal_dr_splitting_slab(problem: str, kernel, b_rows: torch.Tensor, image_s
     from .core.proximal_operators import prox_box
     H, W = int(image_shape[0]), int(image_shape[1])
     sv = SlabSolver(kernel, (H, W), t, t, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
-                    eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True))
+                    eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True), force_exchange=kwargs.get("force_exchange", False), exchange_groups=kwargs.get("exchange_groups", 0))
     try:
         dev, dt = sv.dev, sv.dt
         bd = stage(b_rows, dev, dt)
@@ -401,7 +490,7 @@ def primal_dual_dr_splitting_slab(b_rows: torch.Tensor, kernel, image_shape: Tup
     from .core.proximal_operators import prox_box
     H, W = int(image_shape[0]), int(image_shape[1])
     sv = SlabSolver(kernel, (H, W), t, t, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
-                    eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True))
+                    eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True), force_exchange=kwargs.get("force_exchange", False), exchange_groups=kwargs.get("exchange_groups", 0))
     try:
         lay, dev, dt = sv.lay, sv.dev, sv.dt
         bd = stage(b_rows, dev, dt)
@@ -440,7 +529,7 @@ def chambolle_pock_slab(b_rows: torch.Tensor, kernel, image_shape: Tuple[int, in
     from .plan import stage
     H, W = int(image_shape[0]), int(image_shape[1])
     sv = SlabSolver(kernel, (H, W), 1, 1, dtype=kwargs.get("dtype", b_rows.dtype), device=kwargs.get("device", b_rows.device), group=kwargs.get("group"),
-                    n_spectra=1, eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True))
+                    n_spectra=1, eig_arrays=kwargs.get("eig_arrays"), local_multipliers=kwargs.get("local_multipliers", True), force_exchange=kwargs.get("force_exchange", False), exchange_groups=kwargs.get("exchange_groups", 0))
     try:
         lay, dev, dt = sv.lay, sv.dev, sv.dt
         b2 = b_rows.reshape(lay.rows, W)

@@ -289,6 +289,10 @@ int ddn_slab_loss(ddn_plan* p, int rows, double* record8_dev);
 int ddn_slab_rows_cp(ddn_plan* p, int rows, void* spec_rows_dev, void* spec_aux_dev, void* x_dev, void* z_dev, void* y_dev, const void* b_dev,
                      double t, double s, double gamma, int objective, int step, int consume, int produce);
 int ddn_slab_cols_multiply(ddn_plan* p, void* spec_cols_dev, int tile_lo, int n_tiles_local, int conj, int n_row_blocks);
+/* ddn_slab_cols (mode 0) or ddn_slab_cols_multiply (mode 1: times eK, 2: times conj eK) on `count` of the buffer's
+ * tiles from the first-th on: lets the caller run the column stage of a tile group while the exchange of the next one
+ * is in flight.  No counterpart in the reference (its transform is one fft2 call, mm:110-112). */
+int ddn_slab_cols_part(ddn_plan* p, void* spec_cols, int tile_lo, int n_tiles_local, int n_row_blocks, int mode, int first, int count);
 
 /* Timing hook for bench.py: average duration in milliseconds, measured with HIP
  * events on the plan's stream, of the last *_run call's dominant kernel (the fused

@@ -142,6 +142,40 @@ def _two_rank_worker(rank, world, port, H, W, kname, dtname, N, out):
         dist.destroy_process_group()
 
 
+def _rccl_one_rank_worker(rank, world, port, out):
+    import torch.distributed as dist
+    import convex_optimization_amd.slab as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        H, W, N = 512, 1024, 12
+        kern, b, stA, stP, stC = _problem(H, W, "motion15_45", torch.float32)
+        res = {}
+        plain = S.admm_solver_slab(b, (H, W), "l1", kernel=kern, niters=N, init_state=stA)
+        plain_cp = S.chambolle_pock_slab(b, kern, (H, W), "l1", max_iter=N, init_state=stC)
+        for groups in (0, 1, 3):
+            got = S.admm_solver_slab(b, (H, W), "l1", kernel=kern, niters=N, init_state=stA, force_exchange=True, exchange_groups=groups)
+            res[f"admm_g{groups}"] = float((got - plain).abs().max())
+            got = S.chambolle_pock_slab(b, kern, (H, W), "l1", max_iter=N, init_state=stC, force_exchange=True, exchange_groups=groups)
+            res[f"cp_g{groups}"] = float((got - plain_cp).abs().max())
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_exchange_is_an_identity():
+    """The device-tensor collectives of the exchange (all_to_all_single with uneven splits, all_to_all over tile
+    groups on RCCL's stream, the 4-double all-reduce) run in a one-rank RCCL group: the solve must equal, bit for bit,
+    the one-rank solve that skips the exchange."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_one_rank_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert out[0] and all(v == 0.0 for v in out[0].values()), dict(out[0])
+
+
 @pytest.mark.parametrize("H,W,kname,dtname", [(64, 96, "gauss9", "float32"), (64, 64, "motion15_45", "float64"), (512, 1024, "motion15_45", "float32"),
                                               (4096, 96, "motion15_45", "float32"), (48, 80, "motion15_45", "float32"),
                                               (4096, 32, "gauss9", "float64")])

@@ -37,6 +37,8 @@ namespace {
 
 
 // ------------------------------------------------------------------------------ factorisation
+constexpr int kMaxPrimeRadix = 509;
+
 bool factorize(int n, FftDesc& d) {
     std::memset(&d, 0, sizeof(d));
     d.n = n;
@@ -79,6 +81,13 @@ bool factorize(int n, FftDesc& d) {
         while (rem % p == 0) {
             rad.push_back(p);
             rem /= p;
+        }
+    }
+    // larger prime factors (17 .. kMaxPrimeRadix): the runtime-radix pass of ddn_fft.hpp (O(p) work per element)
+    for (int q = 17; q <= kMaxPrimeRadix && rem > 1; q += 2) {
+        while (rem % q == 0) {
+            rad.push_back(q);
+            rem /= q;
         }
     }
     if (rem != 1) return false;
@@ -1523,7 +1532,7 @@ static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, 
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->num_cu = prop.multiProcessorCount;
     if (!factorize(W, p->fw) || !factorize(H, p->fh)) {
         delete p;
-        return fail(DDN_E_UNSUPPORTED, "plan_create: image size has a prime factor > 13");
+        return fail(DDN_E_UNSUPPORTED, "plan_create: image size has a prime factor > 509");
     }
     const bool ok = dtype == DDN_F32 ? choose_col<float>(p) : choose_col<double>(p);
     if (!ok) {
@@ -1545,7 +1554,7 @@ static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, 
         }
         if (!p->long_R) {
             delete p;
-            return fail(DDN_E_UNSUPPORTED, "plan_create: row length too large (W must be 2, 4, 8 or 16 times a length of at most 4096 with prime factors <= 13)");
+            return fail(DDN_E_UNSUPPORTED, "plan_create: row length too large (W must be 2, 4, 8 or 16 times a length of at most 4096 with prime factors <= 509)");
         }
     }
     int rc = dtype == DDN_F32 ? plan_alloc<float>(p) : plan_alloc<double>(p);

@@ -291,10 +291,63 @@ __device__ __forceinline__ void butterfly(cx<T>* lds, const Tw<T>& tw, int n, in
     for (int q = 0; q < R; ++q) lds[idx[q]] = v[q];
 }
 
+// Pass s with a radix known only at run time (prime factors above 13): one thread per OUTPUT element, direct
+// evaluation of its r-term sum from LDS.  A butterfly's outputs overwrite its own inputs only, so the pass goes in
+// rounds over whole butterflies: compute up to KREG outputs per thread into registers, barrier, store, barrier.
+// Every thread of the workgroup must call it (it contains barriers).
+template <typename T, bool INV>
+__device__ __noinline__ void prime_pass(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
+    constexpr int KREG = 4;
+    const int r = d.radix[s], m = d.m[s], twmul = d.twmul[s], step = d.n / r;
+    const int per = (d.n / r) << cshift;
+    const int total = per * narr;
+    const int per_round = max(1, (nt * KREG) / r);
+    for (int b0 = 0; b0 < total; b0 += per_round) {
+        const int nout = min(per_round, total - b0) * r;
+        cx<T> acc[KREG];
+        int where[KREG];
+#pragma unroll
+        for (int i = 0; i < KREG; ++i) {
+            const int o = tid + i * nt;
+            where[i] = -1;
+            if (o < nout) {
+                const int w = b0 + o / r, q = o % r;
+                const int a = w / per, ww = w - a * per;
+                const int c = ww & ((1 << cshift) - 1), bf = ww >> cshift;
+                const int blk = bf / m, jj = bf - blk * m;
+                const int base = blk * (m * r) + jj, e = jj * twmul;
+                const cx<T>* L = lds + a * arr_stride;
+                cx<T> sum = mk<T>((T)0, (T)0);
+                int aq = 0;                              // (a2 * q) mod r
+                for (int a2 = 0; a2 < r; ++a2) {
+                    cx<T> v = L[SW(((base + a2 * m) << cshift) + c)];
+                    if (INV && m > 1 && a2 > 0) v = mulc(v, tw[a2 * e]);
+                    const cx<T> wq = tw[aq * step];
+                    sum = sum + (INV ? mulc(v, wq) : v * wq);
+                    aq += q;
+                    if (aq >= r) aq -= r;
+                }
+                if (!INV && m > 1 && q > 0) sum = sum * tw[q * e];
+                acc[i] = sum;
+                where[i] = a * arr_stride + SW(((base + q * m) << cshift) + c);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KREG; ++i)
+            if (where[i] >= 0) lds[where[i]] = acc[i];
+        __syncthreads();
+    }
+}
+
 // One full pass over `narr` arrays of n * C elements each (array a starts at lds + a*arr_stride).
 template <typename T, bool INV>
 __device__ __forceinline__ void fft_pass(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
     const int r = d.radix[s], m = d.m[s], ms = d.mshift[s], twmul = d.twmul[s];
+    if (r > 16) {       // uniform over the workgroup
+        prime_pass<T, INV>(lds, narr, arr_stride, tw, d, s, cshift, tid, nt);
+        return;
+    }
     const int per = (d.n / r) << cshift;
     const int total = per * narr;
     for (int w = tid; w < total; w += nt) {

@@ -1,0 +1,42 @@
+"""Image sizes with prime factors above 13 (the reference's torch.fft takes any length: 2-D transforms of 34 x 38 or
+97 x 101 images just work there).  Those factors run in a runtime-radix pass (csrc/ddn_fft.hpp, prime_pass); all four
+solvers against the CPU oracle, fp32 and fp64, and the documented limit: a prime factor above 509 is refused."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ddn_oracle as O  # checker only
+from test_gpu_long_rows import _all_four, _problem, rel, pkg, _fresh_plans  # noqa: F401  (fixtures)
+
+
+@pytest.mark.parametrize("H,W,kname", [(34, 38, "gauss9"), (51, 46, "motion15_45"), (97, 101, "gauss5"), (64, 2 * 127, "gauss9"), (17 * 19, 32, "gauss9")])
+def test_sizes_with_large_prime_factors_fp32(pkg, golden_dir, H, W, kname):
+    kern, b, stC, stA, stP = _problem(golden_dir, H, W, kname, torch.float32)
+    for N in (10, 40):
+        res = _all_four(pkg, kern, b, stC, stA, stP, N)
+        bad = {k: v for k, v in res.items() if not v < 1e-5}
+        assert not bad, (N, res)
+
+
+def test_sizes_with_large_prime_factors_fp64(pkg, golden_dir):
+    """fp64 with the oracle's own eigen arrays injected (the route of the other fp64 parity tests): <= 1e-11."""
+    H, W = 46, 34
+    kern, b, stC, stA, stP = _problem(golden_dir, H, W, "gauss9", torch.float64)
+
+    def eig(t, s):
+        ops = O.DeblurDenoiseOperators(kern, b, t, s)
+        return {"K": ops.eig_arry_K, "D": ops.eig_arry_D1, "M": ops.eig_vals_mat}
+
+    res = _all_four(pkg, kern, b, stC, stA, stP, 20, eig=eig)
+    bad = {k: v for k, v in res.items() if not v < 1e-11}
+    assert not bad, res
+
+
+def test_prime_factor_above_the_limit_is_refused(pkg):
+    """521 is the first prime above the limit: plan creation fails with a message, nothing silently falls back."""
+    from convex_optimization_amd._lib import DdnError
+    b = torch.rand(521, 64)
+    with pytest.raises(DdnError, match="prime factor"):
+        pkg.primal_dr_splitting("l1", torch.ones(3, 3) / 9, b, niters=2)

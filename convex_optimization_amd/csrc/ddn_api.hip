@@ -285,6 +285,19 @@ bool choose_col(ddn_plan* p) {
     if (p->tune_cols > 0) {
         lim = 0;
         while ((1 << lim) < p->tune_cols) ++lim;
+    } else {
+        // Small images on the tile-generic column kernels (one workgroup per tile): with 16-column tiles a 500 x 500
+        // image has 16 workgroups for 256 CUs.  While both half-spectra stay cache-sized (the narrow pieces the row
+        // kernels then write never reach memory as partial lines), narrow the tiles until there is a workgroup per CU.
+        // (Not where a register-resident kernel family applies: those are tied to the wide tiles.  The rule looks at
+        // one image only, so that a batch is solved exactly as its images would be one by one.)
+        auto wave_len = [](int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096; };
+        const bool wave = sizeof(T) == 4 && (wave_len(H) || wave_len(p->W));
+        const size_t spectra = 2 * (size_t)H * p->Wh * sizeof(cx<T>);
+        if (!wave && spectra <= ((size_t)32 << 20)) {
+            const int cus = p->num_cu > 0 ? p->num_cu : 256;
+            while (lim > 0 && ((p->Wh + (1 << lim) - 1) >> lim) < cus) --lim;
+        }
     }
     p->cs = std::min(c2, lim);
     p->ntile = (p->Wh + (1 << p->cs) - 1) >> p->cs;

@@ -512,10 +512,6 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
             w.nyqd = (p->nyqd_on && !fir) ? (float*)p->nyqd : nullptr;
             w.ilv = (p->ilv_on && MODE == COL_RES2) ? 1 : 0;
             w.dbg = p->dbg ? p->dbg + 4096 * 16 : nullptr;  // second half of the stamp buffer
-            if (MODE == COL_MUL && getenv("DDN_COL_STAGGER")) {
-                w.stagger_clks = atoi(getenv("DDN_COL_STAGGER"));
-                w.stagger_first = 2 * p->num_cu + 32;
-            }
             TimerScope ts(p, false);
             if (waven) {
                 w.wtw = (const cx<float>*)p->wtwH;
@@ -1529,7 +1525,7 @@ int static_scratch(double** out) {
 // =============================================================================== C ABI
 extern "C" {
 
-int ddn_version(void) { return 200; }
+int ddn_version(void) { return 210; }
 const char* ddn_last_error(void) { return ddn_err().c_str(); }
 
 static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, void* stream, bool restricted) {

@@ -275,20 +275,6 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
         if (s >= 0 && s < a.lf.iter) return;
     }
     __syncthreads();
-    if (a.stagger_clks > 0 && (int)blockIdx.x < a.stagger_first) {
-        // Two workgroups share a CU and would otherwise run their memory phases and their arithmetic phases at the same
-        // time; the one in the odd wave slot starts late, and every later workgroup inherits the offset from the one it
-        // replaces.  (HW_ID bits 3:0 = wave slot inside the SIMD; the workgroup follows its first wave.)
-        int* const flag = reinterpret_cast<int*>(tiles);
-        if (tid == 0) flag[0] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1);
-        __syncthreads();
-        const int odd = flag[0];
-        __syncthreads();
-        if (odd) {
-            const long long t0 = clock64();
-            while (clock64() - t0 < (long long)a.stagger_clks) __builtin_amdgcn_s_sleep(32);
-        }
-    }
     const int k2q = quarter << 2;                    // first column of the quarter
     const int ncols = min(4, ncol - k2q);
     const int k2 = k2q + wq;                         // this wave's column

@@ -25,8 +25,6 @@ struct Args {
     float scale;
     LossFin lf;
     long long* dbg;        // diagnostic: per-workgroup phase stamps (16 per workgroup) or null
-    int stagger_clks;      // > 0: first-round workgroups in an odd wave slot start this many clocks late (see k_wave_col)
-    int stagger_first;     //   block indices below this count as first round
     int ilv;               // resolvent mode: S0 holds the (S0, S1) pairs interleaved element by element
     int Hfft;              // transform length when lay.H is only a pitch (0: lay.H is both)
     int rb_sh6;            // rows stored in blocks of 64 << rb_sh6 rows (one block per source rank of a row-slab

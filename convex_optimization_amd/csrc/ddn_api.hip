@@ -214,7 +214,8 @@ struct ddn_plan {
     void* ed2 = nullptr;     // |eD|^2 table (Wh entries)
     void* tmp_mult = nullptr;  // scratch multiplier [H][Wp] complex
     double* partials = nullptr;  // [batch*H][4]
-    int* stop = nullptr;         // [batch]
+    int* stop = nullptr;         // [batch] stop flags, then one int of scratch for device-side yes / no answers
+    int* stop_scratch() const { return stop + batch; }
     bool have_K = false, have_G = false, injected = false;
     bool slab_cols = false;      // a column stage over a tile range of a row-slab decomposition: tile-generic kernels only
     int slab_pitch = 0;          // while slab_cols: tile pitch (rows) of the spectral buffers when it is not H
@@ -401,7 +402,7 @@ int plan_alloc(ddn_plan* p) {
         HIPCHK(hipMalloc((void**)&p->dbg, 2 * 4096 * 16 * sizeof(long long)));
         HIPCHK(hipMemset(p->dbg, 0, 2 * 4096 * 16 * sizeof(long long)));
     }
-    HIPCHK(hipMalloc((void**)&p->stop, (size_t)p->batch * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&p->stop, ((size_t)p->batch + 1) * sizeof(int)));
     HIPCHK(hipMemset(p->stop, 0xff, (size_t)p->batch * sizeof(int)));
     return DDN_OK;
 }
@@ -1082,6 +1083,26 @@ int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, doubl
     if (ssim && !p->ssim_prev) HIPCHK(hipMalloc(&p->ssim_prev, plane * sizeof(T)));
     if ((rc = reset_stop<T>(p))) return rc;
     const cx<T>* gc = p->injected ? (const cx<T>*)p->Gc : nullptr;
+    // The two difference duals (D1 == D2, mm:55-59) hold the same bits for the whole run when they start equal -- the
+    // reference starts both from b (pdr:88-89) and updates them by the same expression of the same inputs.  The run then
+    // points both kernel arguments at z21: every second access hits the line the first one brought in (or merges with
+    // its store), so one array's worth of reads and of writes never reaches memory, and z22 is brought up to date by one
+    // copy at the end.  One comparison pass and one copy per run, so only runs of some length take it.
+    bool twin = false;
+    if (n_iters >= 8 && !getenv("DDN_NO_PDR_TWIN")) {
+        int same = 1;
+        HIPCHK(hipMemcpyAsync(p->stop_scratch(), &same, sizeof(int), hipMemcpyHostToDevice, p->stream));
+        hipLaunchKernelGGL(k_same_bits<T>, dim3(ew_grid(plane)), dim3(256), 0, p->stream, (const T*)a.z21, (const T*)a.z22, plane, p->stop_scratch());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&same, p->stop_scratch(), sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        HIPCHK(hipStreamSynchronize(p->stream));
+        twin = same != 0;
+    }
+    struct TwinBack {   // z22 <- z21 when the run ends, however it ends
+        ddn_plan* p; void* dst; const void* src; size_t bytes; bool on;
+        ~TwinBack() { if (on) (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, p->stream); }
+    } twin_back{p, a.z22, a.z21, plane * sizeof(T), twin};
+    if (twin) a.z22 = a.z21;
     if (n_iters > 0) {
         rc0 = row_common<T>(p, cfg.V, false, true);
         if ((rc = launch_solver_row<T, PdrP<T>>(p, cfg, rc0, a))) return rc;

@@ -1350,6 +1350,17 @@ __global__ void k_export_full(const cx<T>* half, cx<T>* out, int H, int W, SpecL
     }
 }
 
+// flag[0] <- 0 when two arrays differ in any bit pattern (flag preset to 1 by the caller)
+template <typename T>
+__global__ void k_same_bits(const T* x, const T* y, size_t n, int* flag) {
+    using U = typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned>::type;
+    const U* a = reinterpret_cast<const U*>(x);
+    const U* b = reinterpret_cast<const U*>(y);
+    bool same = true;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) same = same && a[i] == b[i];
+    if (!same) flag[0] = 0;     // every writer stores the same value
+}
+
 static __global__ void k_iters_done(const int* stop, int* out, int n, int n_iters) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = stop[i] >= 0 ? stop[i] : n_iters;
 }

@@ -586,6 +586,7 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
 struct RowCfg {
     int V, threads, grid;
     size_t lds;
+    bool aligned = false;   // every array of the launch is 16-byte aligned (noted for the split-row pixel kernels)
 };
 
 // Row workgroup shape: V = 4 pixels per lane-access (16 B) and four groups per thread when the
@@ -595,7 +596,7 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
     const int W = p->W;
     if (p->long_R) {
         // rows wider than 8192 pixels: the three-kernel split transform (ddn_long.hpp); V = -1 marks it
-        rc.V = -1; rc.threads = 256; rc.lds = 0; rc.grid = 1;
+        rc.V = -1; rc.threads = 256; rc.lds = 0; rc.grid = 1; rc.aligned = aligned;
         return true;
     }
     // A wavefront of the register-resident kernels works through its rows alone (two transforms and the pixel
@@ -697,6 +698,7 @@ int launch_solver_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, con
         LongArgs<T> la;
         int rc = long_args<T>(p, c, 3, la);
         if (rc) return rc;
+        la.vec = cfg.aligned && p->W % 4 == 0 ? 4 : 1;
         return long_row_launch<T, P>(p->stream, p->num_cu, la, a);
     }
     return row_launch<T, P>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.V, c, a);

@@ -296,8 +296,8 @@ __device__ __forceinline__ void butterfly(cx<T>* lds, const Tw<T>& tw, int n, in
 // rounds over whole butterflies: compute up to KREG outputs per thread into registers, barrier, store, barrier.
 // Every thread of the workgroup must call it (it contains barriers).
 template <typename T, bool INV>
-__device__ __noinline__ void prime_pass(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
-    constexpr int KREG = 4;
+__device__ __forceinline__ void prime_pass(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
+    constexpr int KREG = 2;
     const int r = d.radix[s], m = d.m[s], twmul = d.twmul[s], step = d.n / r;
     const int per = (d.n / r) << cshift;
     const int total = per * narr;
@@ -344,7 +344,7 @@ __device__ __noinline__ void prime_pass(cx<T>* lds, int narr, int arr_stride, co
 template <typename T, bool INV>
 __device__ __forceinline__ void fft_pass(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
     const int r = d.radix[s], m = d.m[s], ms = d.mshift[s], twmul = d.twmul[s];
-    if (r > 16) {       // uniform over the workgroup
+    if (__builtin_expect(r > 16, 0)) {       // uniform over the workgroup; rare: keep it out of the hot path's layout
         prime_pass<T, INV>(lds, narr, arr_stride, tw, d, s, cshift, tid, nt);
         return;
     }

@@ -34,7 +34,10 @@ inline int pix_grid(int num_cu, size_t nrows) { return (int)std::max<size_t>(1, 
 
 template <typename T, class P, int R>
 int pix(hipStream_t st, int num_cu, const LongArgs<T>& a, const typename P::Args& pa) {
-    hipLaunchKernelGGL((dlong::k_long_pix<T, P, R>), dim3(pix_grid(num_cu, (size_t)a.c.batch * a.c.H)), dim3(256), 0, st, a, pa);
+    constexpr int VMAX = 4;     // the width of the policies' vector accesses (four pixels: 16 bytes in float, 2 x 16 in double)
+    const dim3 grid(pix_grid(num_cu, (size_t)a.c.batch * a.c.H));
+    if (a.vec == VMAX && a.M % VMAX == 0) hipLaunchKernelGGL((dlong::k_long_pix<T, P, R, VMAX>), grid, dim3(256), 0, st, a, pa);
+    else hipLaunchKernelGGL((dlong::k_long_pix<T, P, R, 1>), grid, dim3(256), 0, st, a, pa);
     HIPCHK(hipGetLastError());
     return DDN_OK;
 }

@@ -163,36 +163,75 @@ __device__ __forceinline__ void twiddles(const LongArgs<T>& a, int m, cx<T> (&tw
     for (int q = 0; q <= R / 2; ++q) twd[q] = unit<T>((long)m * q, a.c.W);
 }
 
+// V consecutive complex values as one aligned access (two 16-byte accesses for four float pairs)
+template <typename T, int V>
+struct alignas((sizeof(cx<T>) * V) > 16 ? 16 : (sizeof(cx<T>) * V)) CxVec {
+    cx<T> e[V];
+};
+
 // ---- the resolvent solvers (primal DR, primal-dual DR, ADMM): policy step on the R pixels of every m ------------
-template <typename T, class P, int R>
+// A thread owns V consecutive m: its accesses of Y are V complex values wide and the policy's accesses of the
+// iterate arrays V pixels wide (16 bytes for V = 4 floats).  V > 1 needs 16-byte aligned arrays and M % V == 0.
+template <typename T, class P, int R, int V>
 __global__ void __launch_bounds__(256) k_long_pix(LongArgs<T> a, typename P::Args pa) {
     __shared__ double red[16 * 4];
+    constexpr int NQ = R / 2 + 1;
     const int tid = threadIdx.x, nt = blockDim.x, M = a.M, W = a.c.W;
     const size_t nrows = (size_t)a.c.batch * a.c.H;
     for (size_t row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int plane = (int)(row / a.c.H);
         if (a.c.stop && a.c.stop[plane] >= 0) continue;
         double acc[4] = {0, 0, 0, 0};
-        for (int m = tid; m < M; m += nt) {
-            cx<T> twd[R / 2 + 1];
-            twiddles<T, R>(a, m, twd);
-            T u[R], k[R], du[R], re[R], im[R], s[R];
+        for (int m = tid * V; m < M; m += nt * V) {
+            cx<T> twd[V][NQ];
+#pragma unroll
+            for (int v = 0; v < V; ++v) twiddles<T, R>(a, m + v, twd[v]);
+            T px[3][R][V];     // (u, K u, D u) in, then (re, im, s) out: [array][j][v]
             if (a.c.do_consume) {
-                to_pixels<T, R>(a, 0, row, m, twd, u);
-                to_pixels<T, R>(a, 1, row, m, twd, k);
-                to_pixels<T, R>(a, 2, row, m, twd, du);
+#pragma unroll
+                for (int arr = 0; arr < 3; ++arr) {
+                    CxVec<T, V> y[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) y[q] = *reinterpret_cast<const CxVec<T, V>*>(a.Y + y_index(a, arr, row, q, m));
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        cx<T> z[R];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) z[q] = mulc(y[q].e[v], twd[v][q]);   // conj twiddle on the way back
+#pragma unroll
+                        for (int q = NQ; q < R; ++q) z[q] = cconj(z[R - q]);
+                        z[0].y = (T)0;
+                        z[R / 2].y = (T)0;
+                        Dft<T, R, true>::run(z);
+#pragma unroll
+                        for (int j = 0; j < R; ++j) px[arr][j][v] = z[j].x;
+                    }
+                }
             }
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 const size_t o = row * (size_t)W + (size_t)M * j + m;
-                T u1[1] = {u[j]}, k1[1] = {k[j]}, d1[1] = {du[j]}, r1[1], i1[1], s1[1];
-                P::template step<1>(pa, a.c.do_consume != 0, a.c.do_produce != 0, o, u1, k1, d1, r1, i1, s1, acc);
-                re[j] = r1[0]; im[j] = i1[0]; s[j] = s1[0];
+                T r1[V], i1[V], s1[V];
+                P::template step<V>(pa, a.c.do_consume != 0, a.c.do_produce != 0, o, px[0][j], px[1][j], px[2][j], r1, i1, s1, acc);
+#pragma unroll
+                for (int v = 0; v < V; ++v) { px[0][j][v] = r1[v]; px[1][j][v] = i1[v]; px[2][j][v] = s1[v]; }
             }
             if (a.c.do_produce) {
-                from_pixels<T, R>(a, 0, row, m, twd, re);
-                from_pixels<T, R>(a, 1, row, m, twd, im);
-                from_pixels<T, R>(a, 2, row, m, twd, s);
+#pragma unroll
+                for (int arr = 0; arr < 3; ++arr) {
+                    CxVec<T, V> y[NQ];
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        cx<T> z[R];
+#pragma unroll
+                        for (int j = 0; j < R; ++j) z[j] = mk<T>(px[arr][j][v], (T)0);
+                        Dft<T, R, false>::run(z);
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) y[q].e[v] = z[q] * twd[v][q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) *reinterpret_cast<CxVec<T, V>*>(a.Y + y_index(a, arr, row, q, m)) = y[q];
+                }
             }
         }
         if (a.c.do_consume) {

@@ -14,6 +14,7 @@ struct LongArgs {
     FftDesc fm;          // the length-M transform
     const cx<float>* wtw; // per-lane twiddles of the register-resident 4096-point transform (M = 4096, float) or null
     int R, M;
+    int vec;             // pixels per access of the pixel kernels: 1, or 4 when every array is 16-byte aligned and W % 4 == 0
     int narr;            // arrays crossing per direction: 3 (u, K u, D u) / (re, im, s) for the resolvent solvers, 1 otherwise
 };
 

@@ -471,6 +471,7 @@ inline int col_threads_for(const ddn_plan* p, int n, int cs, int narr) {
 
 inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
 
+constexpr double kColStaggerUs = 8.0;   // default delay of the late half of the column stage's first round
 inline bool wcol_ready(const ddn_plan* p) {
     return p->eKc_ok && p->wtw && p->H == 4096 && p->cs == 4 && !p->injected && !p->slab_cols && !getenv("DDN_NO_WAVE_COLS");
 }
@@ -503,7 +504,7 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
             wcol::Args w;
             std::memset(&w, 0, sizeof(w));
             w.S0 = (cx<float>*)p->S0; w.S1 = (cx<float>*)p->S1;
-            w.eKc = (const cx<float>*)p->eKc; w.wtw = (const cx<float>*)p->wtw;
+            w.eKc = (const cx<float>*)p->eKc; w.wtw = (const cx<float>*)p->wtw; w.twH = (const cx<float>*)p->twH;
             w.ed2 = (const float*)p->ed2; w.cK = (float)p->g_cK; w.cD = (float)p->g_cD; w.gscale = (float)(1.0 / ((double)p->H * (double)p->W));
             w.lay = layout_of(p); w.Wh = p->Wh; w.batch = nplanes;
             const bool fir = MODE == COL_MUL && p->nyq_fir_on;   // column W/2 is the row kernels' business
@@ -513,6 +514,12 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
             w.nyqd = (p->nyqd_on && !fir) ? (float*)p->nyqd : nullptr;
             w.ilv = (p->ilv_on && MODE == COL_RES2) ? 1 : 0;
             w.dbg = p->dbg ? p->dbg + 4096 * 16 : nullptr;  // second half of the stamp buffer
+            if (wave1 && MODE == COL_RES2) {
+                // half of the first round starts late (k_wave_col): DDN_COL_STAGGER_US overrides the delay, 0 switches it off
+                static const double stagger_us = getenv("DDN_COL_STAGGER_US") ? atof(getenv("DDN_COL_STAGGER_US")) : kColStaggerUs;
+                w.stagger = (int)(stagger_us * 100.0);
+                w.stagger_blocks = p->num_cu;     // the first round: one eight-wave workgroup per compute unit
+            }
             TimerScope ts(p, false);
             if (waven) {
                 w.wtw = (const cx<float>*)p->wtwH;
@@ -1548,7 +1555,7 @@ int static_scratch(double** out) {
 // =============================================================================== C ABI
 extern "C" {
 
-int ddn_version(void) { return 210; }
+int ddn_version(void) { return 220; }
 const char* ddn_last_error(void) { return ddn_err().c_str(); }
 
 static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, void* stream, bool restricted) {

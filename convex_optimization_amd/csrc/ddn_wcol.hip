@@ -16,7 +16,7 @@ static int wcol_go(hipStream_t st, int grid, const wcol::Args& a) {
 
 int wcol_launch(hipStream_t st, int mode, const wcol::Args& a) {
     if (a.lay.cs != 4) return fail(DDN_E_UNSUPPORTED, "wcol: 16-column spectral tiles only");
-    const int grid = a.batch * 32 * ((a.lay.ntile + 7) / 8);
+    const int grid = a.batch * ((a.Wh + 3) >> 2);   // one workgroup per quarter tile that holds a column
     if (a.rb_extra) {
         // rows stored in per-source blocks (row-slab decomposition): separate spectra
         if (a.ilv || a.nyqd) return fail(DDN_E_UNSUPPORTED, "wcol: row blocks go with separate spectra");

@@ -242,6 +242,44 @@ __device__ __forceinline__ void mul_half(cx<float> (&d)[64], const cx<float>* ec
     }
 }
 
+// Column W/2 with a dense home (one real number per row and spectrum): its workgroup holds no other column, so the
+// whole workgroup transforms it together in LDS -- three radix-16 passes each way, one butterfly per thread and
+// pass -- instead of leaving it to one wavefront per spectrum (the register transform of a lone wavefront takes as
+// long as a whole quarter tile and the launch then ends that much later: 512 quarter tiles are exactly two rounds).
+// The multipliers are read from the column-major copy (4096 entries, natural order); an LDS position p of the
+// digit-reversed spectrum holds frequency ((p >> 8) & 15) + 16 ((p >> 4) & 15) + 256 (p & 15).
+template <int MODE, int NT>
+__device__ __forceinline__ void dense_column(const Args& a, int plane, float* tiles, int tid) {
+    constexpr int NARR = MODE == COL_RES2 ? 2 : 1;
+    cx<float>* const L = reinterpret_cast<cx<float>*>(tiles);
+    const Tw<float> tw = tw_setup<float>(L + NARR * 4096, a.twH, 4096, tid, NT);
+    float* const dc = a.nyqd + (size_t)plane * 2 * 4096;
+    for (int i = tid; i < NARR * 4096; i += NT) L[(i & ~4095) + SW(i & 4095)] = mk<float>(dc[i], 0.f);
+    __syncthreads();
+    fft_forward_fixed<float, 4096, 16>(L, NARR, 4096, tw, 0, tid, NT);
+    const int kc = a.Wh - 1;
+    const cx<float>* const ecol = a.eKc + (size_t)kc * kColPitch;
+    const float cDd = a.cD * a.ed2[kc];
+    for (int p = tid; p < 4096; p += NT) {
+        const int k1 = ((p >> 8) & 15) + (((p >> 4) & 15) << 4) + ((p & 15) << 8);
+        const cx<float> e = ecol[k1];
+        const int i0 = SW(p);
+        if (MODE == COL_RES2) {
+            const cx<float> P = L[i0], Q = L[4096 + i0];
+            const float g = a.gscale / (1.f + a.cK * (e.x * e.x + e.y * e.y) + cDd);
+            const cx<float> U = (P + mulc(Q, e)) * g;
+            L[i0] = U;
+            L[4096 + i0] = e * U;
+        } else {
+            const cx<float> d = L[i0];
+            L[i0] = (a.conj_mult ? mulc(d, e) : d * e) * a.scale;
+        }
+    }
+    __syncthreads();
+    fft_inverse_fixed<float, 4096, 16>(L, NARR, 4096, tw, 0, tid, NT);
+    for (int i = tid; i < NARR * 4096; i += NT) dc[i] = L[(i & ~4095) + SW(i & 4095)].x;
+}
+
 // MODE: COL_RES2 (eight waves: four columns of S0 and of S1) or COL_MUL (four waves: four columns of S0)
 template <int MODE, bool ILV = false, bool RB = false>
 __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Args a) {
@@ -254,19 +292,23 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
     const int cs = a.lay.cs, C = 1 << cs;
     const int ncol = a.Wh;
     const int nq = (ncol + 3) >> 2;                  // quarter tiles with at least one column (tiles are 16 wide: 4 per tile)
-    // block -> (plane, quarter tile): the four workgroups of a tile get indices 8 apart
-    const int per_plane = 32 * ((a.lay.ntile + 7) / 8);
-    const int plane = blockIdx.x / per_plane;
-    const int b = blockIdx.x - plane * per_plane;
-    int quarter;
+    // block -> (plane, quarter tile), nq blocks per plane and none without work.  Within a whole group of eight tiles
+    // (32 blocks) the four workgroups of a tile get indices 8 apart: same XCD, dispatched together.  The quarters of
+    // the last, partial group of tiles (column W/2) come first, one per block: a lone column's job then runs beside the
+    // first round instead of after the last one.
+    const int plane = blockIdx.x / nq;
+    const int b = blockIdx.x - plane * nq;
+    const int nfull = (a.lay.ntile >> 3) << 5, nrest = nq - nfull;
+    int quarter, tgroup;
     {
-        // the last group of eight tiles goes first: it holds the lone column W/2, whose workgroup then
-        // runs beside the first round instead of after the second one
-        const int ngrp4 = 4 * ((a.lay.ntile + 7) / 8);
-        const int x = b & 7;
-        int aa = (b >> 3) + ngrp4 - 4;
-        aa = aa >= ngrp4 ? aa - ngrp4 : aa;
-        quarter = 4 * (8 * (aa >> 2) + x) + (aa & 3);
+        const int bb = b - nrest;
+        if (bb >= 0) {
+            quarter = 4 * (8 * (bb >> 5) + (bb & 7)) + ((bb >> 3) & 3);
+            tgroup = bb >> 5;
+        } else {
+            quarter = nfull + b;
+            tgroup = 0;
+        }
     }
     if (a.lf.enabled && quarter == 0) loss_finalize(a.lf, plane, reinterpret_cast<double*>(tiles), tid, NT);
     if (quarter >= nq) return;
@@ -275,6 +317,15 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
         if (s >= 0 && s < a.lf.iter) return;
     }
     __syncthreads();
+    // Two phases across the chip.  Every workgroup of the first round would load, transform and store at the same time
+    // as all the others: the memory system is then saturated during the load and store phases and idle during the
+    // transforms (a workgroup that happens to run out of step finishes in 32 us instead of 42).  So half of the first
+    // round -- every other group of eight tiles, the four quarters of a tile together, since they share cache lines --
+    // starts about one uncontended load phase late; later rounds inherit the shift.
+    if (a.stagger > 0 && (int)blockIdx.x < a.stagger_blocks && (tgroup & 1)) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (long long)a.stagger) __builtin_amdgcn_s_sleep(8);
+    }
     const int k2q = quarter << 2;                    // first column of the quarter
     const int ncols = min(4, ncol - k2q);
     const int k2 = k2q + wq;                         // this wave's column
@@ -287,17 +338,18 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
     float* const mytile = tiles + (size_t)wv * WFFT_TILE_FLOATS;
 
     // column W/2 with a dense home: its quarter holds nothing else, so the workgroup skips the tile traffic
-    // (the column would use 8 bytes of every 128-byte line) and wave 0 of each half streams the dense array
-    const bool dense = a.nyqd && (a.Wh & 3) == 1 && k2q == a.Wh - 1;
-    float* const dcol = a.nyqd + ((size_t)plane * 2 + h) * 4096;
+    // (the column would use 8 bytes of every 128-byte line) and transforms the dense array in LDS
+    if (a.nyqd && (a.Wh & 3) == 1 && k2q == a.Wh - 1) {
+        if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 6] = wall_clock64();
+        dense_column<MODE, NT>(a, plane, tiles, tid);
+        if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 7] = wall_clock64();
+        return;
+    }
 #define DDN_CSTAMP(i) if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + (i)] = clock64();
     DDN_CSTAMP(0)
     if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16 + 6] = wall_clock64();
     cx<float> d[64];
-    if (dense) {
-#pragma unroll
-        for (int r = 0; r < 64; ++r) d[r] = mk<float>(wq == 0 ? dcol[64 * r + lane] : 0.f, 0.f);
-    } else if (ILV) {
+    if (ILV) {
         load_quarter_ilv(d, reinterpret_cast<const wrow::f4*>(a.S0) + qbase, C, stg0, stg1, wv, lane);
     } else load_quarter<RB>(d, Sarr + qbase, C, stg, wq, lane, a.rb_sh6, (size_t)a.rb_extra);
     pin(d);
@@ -332,12 +384,7 @@ __global__ void __launch_bounds__(MODE == COL_RES2 ? 512 : 256, 2) k_wave_col(Ar
     // offsets kept alive across the kernel would be spilled
     int lane_s = lane;
     asm volatile("" : "+v"(lane_s));
-    if (dense) {
-        if (wq == 0) {
-#pragma unroll
-            for (int r = 0; r < 64; ++r) dcol[64 * r + lane_s] = d[r].x;
-        }
-    } else if (ILV) {
+    if (ILV) {
         store_quarter_ilv(d, reinterpret_cast<wrow::f4*>(a.S0) + opaque(qbase), C, stg0, stg1, wv, lane_s, ncols);
     } else store_quarter<RB>(d, Sarr + opaque(qbase), C, stg, wq, lane_s, ncols, a.rb_sh6, (size_t)a.rb_extra);
     DDN_CSTAMP(5)

@@ -18,6 +18,7 @@ struct Args {
     const float* ed2;      // |eD|^2 per column (Wh entries): the resolvent multiplier is recomputed per frequency,
     float cK, cD, gscale;  //   g = gscale / (1 + cK |e|^2 + cD ed2[k2])  (mm:67-72), which saves reading a third array
     const cx<float>* wtw;  // per-lane twiddles of the 4096-point transform
+    const cx<float>* twH;  // twiddle table of the length-4096 LDS transform (dense column W/2), layout of tw_setup
     SpecLayout lay;
     int Wh, batch;
     float* nyqd;           // dense home of column W/2 (real parts, [batch][2 arrays][H]) or null = inside the last tile
@@ -29,6 +30,8 @@ struct Args {
     int Hfft;              // transform length when lay.H is only a pitch (0: lay.H is both)
     int rb_sh6;            // rows stored in blocks of 64 << rb_sh6 rows (one block per source rank of a row-slab
     long long rb_extra;    //   decomposition): block i starts i * rb_extra elements past its place in a plain tile; 0 = plain
+    int stagger;           // > 0: the workgroups of every other group of eight tiles among the first stagger_blocks blocks start
+    int stagger_blocks;    //   `stagger` ticks of the 100 MHz wall clock late (see k_wave_col)
 };
 
 // Column-major natural-order copies of the multipliers: outc[k2][k1] = tiled[pos(k1)][k2].

@@ -474,9 +474,10 @@ def test_full_size_4096_square_vs_oracle_and_tile_path(pkg, golden_dir, monkeypa
     monkeypatch.delenv("DDN_NO_NYQ_DENSE")
     # Chambolle-Pock with the dense home evaluates column W/2 as a short correlation along the rows inside the row
     # kernels (no column transform): the same numbers up to rounding, not bit for bit
-    assert rel(dense[0].numpy(), tiled[0].numpy()) < 1e-6
-    for g, r in zip(dense[1:], tiled[1:]):
-        assert np.array_equal(g.numpy(), r.numpy())
+    # the resolvent solvers transform the dense column W/2 with the whole workgroup in LDS (radix-16 passes) instead of
+    # the register transform of the tile path: the same numbers up to rounding as well
+    for g, r in zip(dense, tiled):
+        assert rel(g.numpy(), r.numpy()) < 1e-6
 
 
 def test_fused_ssim_vs_reference_golden_and_oracle(pkg, golden_dir):

@@ -18,9 +18,10 @@ L.check(lib.ddn_pdr_run(ops.plan._h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 2.0, 0.1
 torch.cuda.synchronize()
 buf = np.zeros((8192, 16), dtype=np.int64)
 L.check(lib.ddn_plan_debug_stamps(ops.plan._h, buf.ctypes.data_as(C.c_void_p), 8192))
-c = buf[4096:4096 + 544, :6]
+c = buf[4096:4096 + 544, :6]  # (513 blocks per image)
 w = buf[4096:4096 + 544, 6:8]
 ok = c[:, 5] > 0
+dn = (w[:, 1] > 0) & ~ok   # the dense column-W/2 job stamps its wall-clock start and end only
 print("column workgroups with stamps:", ok.sum())
 t0 = c[ok, 0].min()
 d = np.diff(c[ok], axis=1).astype(np.float64)
@@ -38,6 +39,8 @@ w0 = wk[:, 0].min()
 ws = (wk[:, 0] - w0) / 100.0
 we = (wk[:, 1] - w0) / 100.0
 print("wall-clock (us, 100 MHz counter): kernel span", we.max())
+for i in np.nonzero(dn)[0]:
+    print("dense column job: block", int(i), "start", (w[i, 0] - w0) / 100.0, "end", (w[i, 1] - w0) / 100.0)
 o = np.argsort(ws)
 print("start times sorted, every 32nd:", np.round(ws[o][::32], 1))
 print("end times sorted, every 32nd:  ", np.round(np.sort(we)[::32], 1))
@@ -49,3 +52,13 @@ print("second-round starts histogram (us):", np.histogram(ws[(ws >= 5)], bins=[5
 print("block 0 phases (ticks):", np.diff(c[0]).tolist())
 print("block 8 phases (ticks):", np.diff(c[8]).tolist())
 print("last block phases (ticks):", np.diff(c[idx[np.argmax(we)]]).tolist())
+# workgroups that start out of step with the rest (the CU of the short column-W/2 job takes its next jobs early):
+# their phase durations show what a job costs when the other CUs are not in the same phase
+odd = [i for i in range(len(ws)) if (5 < ws[i] < 38) or ws[i] > 56]
+for i in odd[:12]:
+    print("out-of-step WG block", int(idx[i]), "start", round(ws[i], 1), "end", round(we[i], 1), "phases (us):", np.round(np.diff(c[idx[i]]) / 2100.0, 1).tolist())
+# phase durations by start time: first-round workgroups that started on time, late ones, second round
+for nm, sel in (("first round, on time", ws < 2), ("first round, late", (ws >= 2) & (ws < 30)), ("second round", ws >= 30)):
+    if sel.sum():
+        ph = np.diff(c[idx[sel]], axis=1) / 2100.0
+        print(f"{nm:22s} n={int(sel.sum()):4d} start {ws[sel].mean():6.1f} end {we[sel].mean():6.1f}  phases (us) load {ph[:,0].mean():5.1f} fft {ph[:,1].mean():5.1f} pointwise {ph[:,2].mean():5.1f} ifft {ph[:,3].mean():5.1f} store {ph[:,4].mean():5.1f}")

@@ -3,8 +3,9 @@
 
 Everything is evaluated by libddn on the GPU: eigenvalue arrays come from the library's own 2-D
 transform of the impulse response, operator applications are real-to-complex / complex-to-real
-round trips with Hermitian-symmetrised multipliers.  Results are returned as complex tensors with a
-zero imaginary part where the reference returns complex tensors (its imaginary parts are roundoff).
+round trips with Hermitian-symmetrised multipliers.  The operator class returns complex tensors with a
+zero imaginary part where the reference returns complex tensors whose imaginary parts are roundoff;
+apply_periodic_conv_2d itself returns the full complex result for any multiplier array.
 """
 from __future__ import annotations
 
@@ -39,17 +40,38 @@ def eig_vals_for_periodic_conv_op(filter_kernel, num_rows: int, num_cols: int, *
 
 
 def apply_periodic_conv_2d(x: torch.Tensor, eig_val_arr: torch.Tensor, **kwargs) -> torch.Tensor:
-    """ifft2(eig_val_arr * fft2(x)) for a real m x n image x (apply_periodic_conv_2d.py:3-28)."""
+    """ifft2(eig_val_arr * fft2(x)) as a complex m x n tensor, for a real or complex image x and ANY complex
+    multiplier array (apply_periodic_conv_2d.py:3-28).
+
+    The library transforms real images with Hermitian multipliers.  A general multiplier e splits into two Hermitian
+    ones, e = eh + i ea with eh[k] = (e[k] + conj(e[-k])) / 2 and ea = the same part of -i e, so for a real image
+    ifft2(e fft2(x)) = A_eh x + i A_ea x, two real applications (the library symmetrises what it is handed, so the
+    second one is simply the multiplier -i e).  A complex image x = xr + i xi takes four:
+    (A_eh xr - A_ea xi) + i (A_ea xr + A_eh xi).  For the eigenvalue array of a real kernel ea is roundoff, as is the
+    imaginary part the reference returns."""
     src = x.device
-    dt = real_dtype(x.dtype)
+    dt = real_dtype(x.real.dtype if x.is_complex() else x.dtype)
     dev = compute_device(kwargs.get("device", src))
     H, W = x.shape
+    e = torch.as_tensor(eig_val_arr)
+    if not e.is_complex():
+        e = torch.complex(e, torch.zeros_like(e))
+    e_rot = e * torch.tensor(-1j, dtype=e.dtype, device=e.device)
     plan = Plan(H, W, 1, dt, dev)
     try:
-        y = plan.apply_multiplier(eig_val_arr, stage(x, dev, dt).reshape(1, H, W))
+        def both(v):
+            vd = stage(v, dev, dt).reshape(1, H, W)
+            return plan.apply_multiplier(e, vd)[0], plan.apply_multiplier(e_rot, vd)[0]
+        if x.is_complex():
+            hr, ar = both(x.real)
+            hi, ai = both(x.imag)
+            y = torch.complex(hr - ai, ar + hi)
+        else:
+            h, a = both(x)
+            y = torch.complex(h, a)
     finally:
         plan.close()
-    return torch.complex(y[0], torch.zeros_like(y[0])).to(src)
+    return y.to(src)
 
 
 class DeblurDenoiseOperators:

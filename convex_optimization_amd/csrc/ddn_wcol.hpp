@@ -251,19 +251,34 @@ __device__ __forceinline__ void mul_half(cx<float> (&d)[64], const cx<float>* ec
 template <int MODE, int NT>
 __device__ __forceinline__ void dense_column(const Args& a, int plane, float* tiles, int tid) {
     constexpr int NARR = MODE == COL_RES2 ? 2 : 1;
+    constexpr int PER = 4096 / NT;                   // spectrum entries per thread
     cx<float>* const L = reinterpret_cast<cx<float>*>(tiles);
-    const Tw<float> tw = tw_setup<float>(L + NARR * 4096, a.twH, 4096, tid, NT);
     float* const dc = a.nyqd + (size_t)plane * 2 * 4096;
-    for (int i = tid; i < NARR * 4096; i += NT) L[(i & ~4095) + SW(i & 4095)] = mk<float>(dc[i], 0.f);
-    __syncthreads();
-    fft_forward_fixed<float, 4096, 16>(L, NARR, 4096, tw, 0, tid, NT);
     const int kc = a.Wh - 1;
     const cx<float>* const ecol = a.eKc + (size_t)kc * kColPitch;
+    // every global read of the job is issued here, before the first wait: one memory latency instead of three in a row
+    cx<float> ev[PER];
+    float in[NARR * PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int p = tid + k * NT;
+        ev[k] = ecol[((p >> 8) & 15) + (((p >> 4) & 15) << 4) + ((p & 15) << 8)];
+    }
+#pragma unroll
+    for (int k = 0; k < NARR * PER; ++k) in[k] = dc[tid + k * NT];
     const float cDd = a.cD * a.ed2[kc];
-    for (int p = tid; p < 4096; p += NT) {
-        const int k1 = ((p >> 8) & 15) + (((p >> 4) & 15) << 4) + ((p & 15) << 8);
-        const cx<float> e = ecol[k1];
-        const int i0 = SW(p);
+    const Tw<float> tw = tw_setup<float>(L + NARR * 4096, a.twH, 4096, tid, NT);
+#pragma unroll
+    for (int k = 0; k < NARR * PER; ++k) {
+        const int i = tid + k * NT;
+        L[(i & ~4095) + SW(i & 4095)] = mk<float>(in[k], 0.f);
+    }
+    __syncthreads();
+    fft_forward_fixed<float, 4096, 16>(L, NARR, 4096, tw, 0, tid, NT);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const cx<float> e = ev[k];
+        const int i0 = SW(tid + k * NT);
         if (MODE == COL_RES2) {
             const cx<float> P = L[i0], Q = L[4096 + i0];
             const float g = a.gscale / (1.f + a.cK * (e.x * e.x + e.y * e.y) + cDd);

@@ -250,3 +250,13 @@ def test_plan_cache_reuses_set_up(pkg, golden_dir):
     assert P.plan_cache_stats()["parked"] <= 2
     P.clear_plan_cache()
     assert P.plan_cache_stats()["parked"] == 0
+
+
+def test_second_device_after_first_in_one_process(pkg, golden_dir):
+    """One process, two GPUs: a solve on cuda:0 and then the same solve on cuda:1 (the kernels' dynamic-LDS attribute and
+    the static scratch address are per device).  Skipped on a one-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    kern, b = _problem(golden_dir, 512)
+    outs = [pkg.primal_dr_splitting("l1", kern, b, niters=5, loss_function=pkg.core.mse, tol=-1.0, device=f"cuda:{i}") for i in (0, 1)]
+    assert np.array_equal(outs[0].cpu().numpy(), outs[1].cpu().numpy())

@@ -32,6 +32,9 @@ DDN_DECL_ROW(double)
     extern template int long_plain_launch<T>(hipStream_t, int, const LongArgs<T>&, const T*, T*, T);
 DDN_DECL_LONG(float)
 DDN_DECL_LONG(double)
+extern template int whole_row_launch<PdrP<float>>(hipStream_t, int, const WholeRowArgs&, const PdrP<float>::Args&);
+extern template int whole_row_launch<PddrP<float>>(hipStream_t, int, const WholeRowArgs&, const PddrP<float>::Args&);
+extern template int whole_row_launch<AdmmP<float>>(hipStream_t, int, const WholeRowArgs&, const AdmmP<float>::Args&);
 
 namespace {
 
@@ -193,6 +196,7 @@ struct ddn_plan {
     int long_R = 0, long_M = 0;
     FftDesc fl{};              // the length-long_M transform
     void* twL = nullptr;       // its twiddle table
+    void* twHalf = nullptr;    // twiddle table of length W / 2 for the whole-row kernels (W = 16384 / 32768, float), or null
     void* edL = nullptr;       // analytic row-spectral D, eD[k] = 1 - w_W^k, k <= W/2
     void* Ylong = nullptr;     // [3][rows][R/2 + 1][M] complex, sized for Ylong_rows rows
     size_t Ylong_rows = 0;
@@ -379,6 +383,7 @@ int plan_alloc(ddn_plan* p) {
     }
     if (p->long_R) {
         if ((rc = make_table<T>(p->long_M, (cx<T>**)&p->twL))) return rc;
+        if (sizeof(T) == 4 && whole_row_width(p->W) && (rc = make_table<T>(p->W / 2, (cx<T>**)&p->twHalf))) return rc;
         std::vector<cx<T>> ed((size_t)p->Wh + 64);
         for (int k = 0; k < p->Wh; ++k) {
             const long double ang = -2.0L * 3.14159265358979323846264338327950288L * k / p->W;
@@ -702,6 +707,15 @@ template <typename T, class P>
 int launch_solver_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, const typename P::Args& a) {
     TimerScope ts(p, true, c.do_consume && c.do_produce);
     if (cfg.V == -1) {
+        if constexpr (sizeof(T) == 4) {
+            // rows of 16384 / 32768 pixels with the two-tap D: the row in one workgroup's LDS (ddn_wholerow.hpp)
+            if (p->twHalf && !p->injected && cfg.aligned && !getenv("DDN_NO_WHOLE_ROWS")) {
+                WholeRowArgs wa;
+                wa.c = c;
+                wa.twHalf = (const cx<float>*)p->twHalf;
+                return whole_row_launch<P>(p->stream, p->num_cu, wa, a);
+            }
+        }
         LongArgs<T> la;
         int rc = long_args<T>(p, c, 3, la);
         if (rc) return rc;
@@ -1555,7 +1569,7 @@ int static_scratch(double** out) {
 // =============================================================================== C ABI
 extern "C" {
 
-int ddn_version(void) { return 220; }
+int ddn_version(void) { return 230; }
 const char* ddn_last_error(void) { return ddn_err().c_str(); }
 
 static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, void* stream, bool restricted) {
@@ -1640,7 +1654,7 @@ int ddn_slab_restrict(ddn_plan* p, int tile_lo, int n_tiles_local) {
 
 int ddn_plan_destroy(ddn_plan* p) {
     if (!p) return DDN_OK;
-    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->twL, p->edL, p->Ylong, p->nyqd, p->ssim_part, p->ssim_val, p->ssim_prev, p->nyq_taps, p->eKc, p->ctab, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
+    void* bufs[] = {p->twW, p->wtw, p->wtwW, p->wtwH, p->twL, p->twHalf, p->edL, p->Ylong, p->nyqd, p->ssim_part, p->ssim_val, p->ssim_prev, p->nyq_taps, p->eKc, p->ctab, p->Gcm, p->twH, p->twA, p->twB, p->S0, p->eK, p->G, p->Gc, p->eDrow, p->ed2, p->tmp_mult, p->partials, p->stop};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : p->ev_pool) {

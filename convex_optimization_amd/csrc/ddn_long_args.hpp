@@ -28,3 +28,13 @@ int long_plain_launch(hipStream_t st, int num_cu, const LongArgs<T>& a, const T*
 // M = 4096, float: the frequency-side kernels with wave-resident transforms (ddn_longw.hip)
 bool long_wave_ok(const LongArgs<float>& a);
 int long_wave_launch(hipStream_t st, int num_cu, const LongArgs<float>& a, bool inverse);
+
+// Rows of 16384 / 32768 pixels, float, two-tap D: one workgroup per row with the row in LDS (ddn_wholerow.hpp),
+// no intermediate array in memory.
+struct WholeRowArgs {
+    RowCommon<float> c;        // twW: the table exp(-2 pi i k / W); S0, S1, lay, stop, partials, do_consume, do_produce
+    const cx<float>* twHalf;   // twiddle table of the length-W/2 transform (layout of make_table)
+};
+bool whole_row_width(int W);
+template <class P>
+int whole_row_launch(hipStream_t st, int num_cu, const WholeRowArgs& a, const typename P::Args& pa);

@@ -457,15 +457,25 @@ inline LossFin no_loss() {
     return lf;
 }
 
-template <typename T, int MODE>
-int launch_col_one(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t lds) {
-    auto fn = k_col<T, MODE>;
+template <typename T, int MODE, int NF>
+int launch_col_fn(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t lds) {
+    auto fn = k_col<T, MODE, NF>;
     int rc = ensure_lds_attr((const void*)fn);
     if (rc) return rc;
     TimerScope ts(p, false);
     hipLaunchKernelGGL(fn, dim3(nblocks), dim3(threads), lds, p->stream, a);
     HIPCHK(hipGetLastError());
     return DDN_OK;
+}
+template <typename T, int MODE>
+int launch_col_one(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t lds) {
+    if constexpr (sizeof(T) == 4) {
+        // the two factors of a 32768-row column (128 x 256): straight-line transforms instead of the run-time radix code
+        static const bool generic_only = getenv("DDN_NO_FIXED_COLS") != nullptr;
+        if (!generic_only && a.fd.n == 256) return launch_col_fn<T, MODE, 256>(p, a, nblocks, threads, lds);
+        if (!generic_only && a.fd.n == 128) return launch_col_fn<T, MODE, 128>(p, a, nblocks, threads, lds);
+    }
+    return launch_col_fn<T, MODE, 0>(p, a, nblocks, threads, lds);
 }
 
 inline int col_threads_for(const ddn_plan* p, int n, int cs, int narr) {

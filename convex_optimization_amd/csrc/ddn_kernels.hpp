@@ -325,7 +325,9 @@ struct ColArgs {
     long long rb_extra;  //   row r lives rb_extra * (r >> rb_shift) rows past its place in a plain tile; 0 = plain
 };
 
-template <typename T, int MODE>
+// NF > 0: the transform length is NF, with the compile-time radix schedule of ddn_fft.hpp (the same digit order as the
+// run-time one, so stored multipliers agree); NF = 0: any length, run-time schedule.
+template <typename T, int MODE, int NF = 0>
 __global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -386,9 +388,9 @@ __global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
     }
     __syncthreads();
     if ((MODE == COL_FWD || MODE == COL_FWD2) && a.dir == 1) {
-        fft_inverse<T>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
+        fft_inv<T, NF, 16>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
     } else {
-        fft_forward<T>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
+        fft_fwd<T, NF, 16>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
     }
     if (MODE != COL_FWD && MODE != COL_FWD2) {
         for (int i0 = tid; i0 < total; i0 += nt * UN) {
@@ -427,7 +429,7 @@ __global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
             }
         }
         __syncthreads();
-        fft_inverse<T>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
+        fft_inv<T, NF, 16>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
     }
     for (int i = tid; i < total; i += nt) {
         const int c = i & (C - 1), e = i >> cs;

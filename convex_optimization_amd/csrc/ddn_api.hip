@@ -469,11 +469,18 @@ int launch_col_fn(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t l
 }
 template <typename T, int MODE>
 int launch_col_one(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t lds) {
-    if constexpr (sizeof(T) == 4) {
-        // the two factors of a 32768-row column (128 x 256): straight-line transforms instead of the run-time radix code
-        static const bool generic_only = getenv("DDN_NO_FIXED_COLS") != nullptr;
-        if (!generic_only && a.fd.n == 256) return launch_col_fn<T, MODE, 256>(p, a, nblocks, threads, lds);
-        if (!generic_only && a.fd.n == 128) return launch_col_fn<T, MODE, 128>(p, a, nblocks, threads, lds);
+    // straight-line transforms instead of the run-time radix code for the lengths the large configurations use: the
+    // factors of a 32768-row column (128 x 256) and of a 4096-row column that is split (64 x 64: float64, slab plans);
+    // 512 rows in float64 (the 512 x 512 parity configuration)
+    static const bool generic_only = getenv("DDN_NO_FIXED_COLS") != nullptr;
+    if (!generic_only) {
+        if (a.fd.n == 64) return launch_col_fn<T, MODE, 64>(p, a, nblocks, threads, lds);
+        if constexpr (sizeof(T) == 4) {
+            if (a.fd.n == 256) return launch_col_fn<T, MODE, 256>(p, a, nblocks, threads, lds);
+            if (a.fd.n == 128) return launch_col_fn<T, MODE, 128>(p, a, nblocks, threads, lds);
+        } else {
+            if (a.fd.n == 512) return launch_col_fn<T, MODE, 512>(p, a, nblocks, threads, lds);
+        }
     }
     return launch_col_fn<T, MODE, 0>(p, a, nblocks, threads, lds);
 }

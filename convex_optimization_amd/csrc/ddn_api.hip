@@ -196,7 +196,7 @@ struct ddn_plan {
     int long_R = 0, long_M = 0;
     FftDesc fl{};              // the length-long_M transform
     void* twL = nullptr;       // its twiddle table
-    void* twHalf = nullptr;    // twiddle table of length W / 2 for the whole-row kernels (W = 16384 / 32768, float), or null
+    void* twHalf = nullptr;    // twiddle table of length W / 2 for the whole-row kernels (W = 8192 / 16384 / 32768, float), or null
     void* edL = nullptr;       // analytic row-spectral D, eD[k] = 1 - w_W^k, k <= W/2
     void* Ylong = nullptr;     // [3][rows][R/2 + 1][M] complex, sized for Ylong_rows rows
     size_t Ylong_rows = 0;
@@ -381,9 +381,9 @@ int plan_alloc(ddn_plan* p) {
         HIPCHK(hipMalloc(dst, tab.size() * sizeof(cx<float>)));
         HIPCHK(hipMemcpy(*dst, tab.data(), tab.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
     }
+    if (sizeof(T) == 4 && whole_row_width(p->W) && (rc = make_table<T>(p->W / 2, (cx<T>**)&p->twHalf))) return rc;
     if (p->long_R) {
         if ((rc = make_table<T>(p->long_M, (cx<T>**)&p->twL))) return rc;
-        if (sizeof(T) == 4 && whole_row_width(p->W) && (rc = make_table<T>(p->W / 2, (cx<T>**)&p->twHalf))) return rc;
         std::vector<cx<T>> ed((size_t)p->Wh + 64);
         for (int k = 0; k < p->Wh; ++k) {
             const long double ang = -2.0L * 3.14159265358979323846264338327950288L * k / p->W;
@@ -645,6 +645,12 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
         // one wavefront per row, eight per CU (256 registers each), the row held in registers
         rc.V = 0; rc.threads = 64; rc.lds = 0;
         rc.grid = std::max(1, std::min(work_items, p->num_cu * 8));
+        return true;
+    }
+    if (sizeof(T) == 4 && !cp && p->twHalf && !p->injected && aligned && !getenv("DDN_NO_WHOLE_ROWS")) {
+        // 8192-pixel rows of the resolvent solvers: the whole-row kernel (ddn_wholerow.hpp) instead of scalar accesses
+        // and the run-time transform below; V = -1 is resolved in launch_solver_row
+        rc.V = -1; rc.threads = 256; rc.lds = 0; rc.grid = 1; rc.aligned = aligned;
         return true;
     }
     if (aligned && W % 4 == 0 && W <= 4096) {
@@ -1586,7 +1592,7 @@ int static_scratch(double** out) {
 // =============================================================================== C ABI
 extern "C" {
 
-int ddn_version(void) { return 230; }
+int ddn_version(void) { return 240; }
 const char* ddn_last_error(void) { return ddn_err().c_str(); }
 
 static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, void* stream, bool restricted) {

@@ -5,7 +5,7 @@
 #include "ddn_launch.hpp"
 #include "ddn_wholerow.hpp"
 
-bool whole_row_width(int W) { return W == 16384 || W == 32768; }
+bool whole_row_width(int W) { return W == 8192 || W == 16384 || W == 32768; }
 
 template <class P, int NH, int NT>
 static int go1(hipStream_t st, int grid, const WholeRowArgs& a, const typename P::Args& pa) {
@@ -29,7 +29,12 @@ int whole_row_launch(hipStream_t st, int num_cu, const WholeRowArgs& a, const ty
     const int grid = (int)std::max<size_t>(1, std::min<size_t>(nrows, (size_t)num_cu));   // 128 KB of LDS: one workgroup per CU
     if (a.c.W == 32768) return go<P, 16384>(st, grid, a, pa);
     if (a.c.W == 16384) return go<P, 8192>(st, grid, a, pa);
-    return fail(DDN_E_UNSUPPORTED, "whole-row kernel: rows of 16384 or 32768 pixels only");
+    if (a.c.W == 8192) {
+        // 35 KB of LDS and 256 threads: several rows per CU
+        const int g2 = (int)std::max<size_t>(1, std::min<size_t>(nrows, (size_t)num_cu * 4));
+        return go1<P, 4096, 256>(st, g2, a, pa);
+    }
+    return fail(DDN_E_UNSUPPORTED, "whole-row kernel: rows of 8192, 16384 or 32768 pixels only");
 }
 
 template int whole_row_launch<PdrP<float>>(hipStream_t, int, const WholeRowArgs&, const PdrP<float>::Args&);

@@ -78,11 +78,13 @@ def _oracle(kern, b, stA, stP, stC, N):
 
 @pytest.mark.parametrize("H,W,kname,dt", [(64, 64, "gauss9", torch.float32), (48, 80, "motion15_45", torch.float32), (64, 64, "gauss9", torch.float64),
                                           (32, 1024, "motion15_45", torch.float32), (16, 4096, "motion15_45", torch.float32),
-                                          (4096, 64, "motion15_45", torch.float32), (1024, 48, "gauss9", torch.float32)])
+                                          (4096, 64, "motion15_45", torch.float32), (1024, 48, "gauss9", torch.float32),
+                                          (16, 8192, "motion15_45", torch.float32)])
 def test_one_rank_slab_path_vs_oracle(H, W, kname, dt):
     """World size 1: the slab entry points (row stage on its own buffer layout, tile-range column stage)
     reproduce the oracle; covers the LDS row kernels, the register-resident row kernels (W = 1024, 4096),
-    the register-resident column kernels on a tile range (H = 4096, 1024) and fp64."""
+    the register-resident column kernels on a tile range (H = 4096, 1024), the whole-row kernel on the slab's
+    spectral layout (W = 8192) and fp64."""
     import convex_optimization_amd.slab as S
     from convex_optimization_amd import _lib
     _lib.lib()
@@ -178,7 +180,7 @@ def test_one_rank_rccl_exchange_is_an_identity():
 
 @pytest.mark.parametrize("H,W,kname,dtname", [(64, 96, "gauss9", "float32"), (64, 64, "motion15_45", "float64"), (512, 1024, "motion15_45", "float32"),
                                               (4096, 96, "motion15_45", "float32"), (48, 80, "motion15_45", "float32"),
-                                              (4096, 32, "gauss9", "float64")])
+                                              (4096, 32, "gauss9", "float64"), (32, 8192, "gauss9", "float32")])
 def test_two_ranks_share_one_image(H, W, kname, dtname):
     """Two ranks, each owning half of the rows, against the single-GPU solve of the whole image (and the
     oracle at the small sizes): all-to-all both ways around every column stage, uneven tile spans,

@@ -647,8 +647,8 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
         rc.grid = std::max(1, std::min(work_items, p->num_cu * 8));
         return true;
     }
-    if (sizeof(T) == 4 && !cp && p->twHalf && !p->injected && aligned && !getenv("DDN_NO_WHOLE_ROWS")) {
-        // 8192-pixel rows of the resolvent solvers: the whole-row kernel (ddn_wholerow.hpp) instead of scalar accesses
+    if (sizeof(T) == 4 && p->twHalf && !p->injected && aligned && !getenv("DDN_NO_WHOLE_ROWS")) {
+        // 8192-pixel rows: the whole-row kernel (ddn_wholerow.hpp) instead of scalar accesses
         // and the run-time transform below; V = -1 is resolved in launch_solver_row
         rc.V = -1; rc.threads = 256; rc.lds = 0; rc.grid = 1; rc.aligned = aligned;
         return true;
@@ -752,6 +752,14 @@ template <typename T>
 int launch_cp_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, const CpArgs<T>& a) {
     TimerScope ts(p, true, c.do_consume && c.do_produce);
     if (cfg.V == -1) {
+        if constexpr (sizeof(T) == 4) {
+            if (p->twHalf && !p->injected && cfg.aligned && !getenv("DDN_NO_WHOLE_ROWS")) {
+                WholeRowArgs wa;
+                wa.c = c;
+                wa.twHalf = (const cx<float>*)p->twHalf;
+                return whole_row_cp_launch(p->stream, p->num_cu, wa, a);
+            }
+        }
         if (p->injected) return fail(DDN_E_UNSUPPORTED, "chambolle_pock with injected eigen arrays: rows wider than 8192 pixels are not supported");
         LongArgs<T> la;
         int rc = long_args<T>(p, c, 1, la);

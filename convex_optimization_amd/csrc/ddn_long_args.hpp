@@ -38,3 +38,4 @@ struct WholeRowArgs {
 bool whole_row_width(int W);
 template <class P>
 int whole_row_launch(hipStream_t st, int num_cu, const WholeRowArgs& a, const typename P::Args& pa);
+int whole_row_cp_launch(hipStream_t st, int num_cu, const WholeRowArgs& a, const CpArgs<float>& pa);

@@ -40,3 +40,22 @@ int whole_row_launch(hipStream_t st, int num_cu, const WholeRowArgs& a, const ty
 template int whole_row_launch<PdrP<float>>(hipStream_t, int, const WholeRowArgs&, const PdrP<float>::Args&);
 template int whole_row_launch<PddrP<float>>(hipStream_t, int, const WholeRowArgs&, const PddrP<float>::Args&);
 template int whole_row_launch<AdmmP<float>>(hipStream_t, int, const WholeRowArgs&, const AdmmP<float>::Args&);
+
+template <int NH, int NT>
+static int go_cp(hipStream_t st, int grid, const WholeRowArgs& a, const CpArgs<float>& pa) {
+    auto fn = wholerow::k_row_whole_cp<NH, NT>;
+    int rc = ensure_lds_attr((const void*)fn);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(NT), wholerow::lds_bytes<NH>(), st, a, pa);
+    HIPCHK(hipGetLastError());
+    return DDN_OK;
+}
+
+int whole_row_cp_launch(hipStream_t st, int num_cu, const WholeRowArgs& a, const CpArgs<float>& pa) {
+    const size_t nrows = (size_t)a.c.batch * a.c.H;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>(nrows, (size_t)num_cu));
+    if (a.c.W == 32768) return go_cp<16384, 512>(st, grid, a, pa);
+    if (a.c.W == 16384) return go_cp<8192, 512>(st, grid, a, pa);
+    if (a.c.W == 8192) return go_cp<4096, 256>(st, (int)std::max<size_t>(1, std::min<size_t>(nrows, (size_t)num_cu * 4)), a, pa);
+    return fail(DDN_E_UNSUPPORTED, "whole-row kernel: rows of 8192, 16384 or 32768 pixels only");
+}

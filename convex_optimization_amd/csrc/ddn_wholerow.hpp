@@ -8,11 +8,11 @@
 // transform holds the pixels of the unnormalised length-W inverse.  So the iteration's row stage (the reference's
 // ifft2 / fft2 along the rows, apply_periodic_conv_2d.py:28, with the per-pixel updates of the solver loops between
 // them) runs per row as
-//     u  = inverse(S0)  -> registers (32 pixels per thread, four consecutive ones per 16-byte access)
+//     u  = inverse(S0)  -> registers (64 pixels per thread at 32768, four consecutive ones per 16-byte access)
 //     Ku = inverse(S1)  -> read from LDS by the pixel step; D u is the two-tap difference of u (multiplying_matrix.py:55-59)
 //     the solver policy's step (the same P::step as every other row kernel): prox / dual / relaxation updates, loss sums
 //     S1 = forward(im), S0 = forward(re + D^T s)
-// with 512 or 1024 threads (one or two radix-16 butterflies per thread and pass) and nothing written to memory between the transforms
+// with 512 threads (256 at 8192 pixels) and nothing written to memory between the transforms
 // -- the three-kernel split transform of ddn_long.hpp moves every transformed array through memory twice more.
 #pragma once
 #include "ddn_kernels.hpp"
@@ -39,13 +39,13 @@ __device__ __forceinline__ cx<float> times_i(cx<float> a) { return mk<float>(-a.
 // Half-spectrum X[0 .. NH] of a real row (global, tiled) -> Z' at the digit-reversed LDS positions the inverse
 // transform starts from.  No barrier inside.  A thread owns the pairs (k, NH - k), k = tid + i kThreads < NH / 2, and
 // issues all of its global loads before the first use (a loop of load-use-load would be a chain of memory round
-// trips: 16 per pass; here four groups of twelve loads); thread 0 also takes the self-paired term k = NH / 2.
+// trips: 16 per pass; here groups of 24 loads); thread 0 also takes the self-paired term k = NH / 2.
 template <int NH, int kThreads>
 __device__ __forceinline__ void spectrum_to_lds(cx<float>* L, const cx<float>* S, const SpecRow& sr, const cx<float>* wW, int tid) {
     // (an opaque copy of the thread index: the unrolled addresses below would otherwise be hoisted out of the row loop
     // as a hundred loop invariants and spilled)
     asm volatile("" : "+v"(tid));
-    constexpr int PER = NH / 2 / kThreads, G = PER < DDN_WHOLE_G ? PER : DDN_WHOLE_G;    // loads in flight per thread: 3 G (more would spill)
+    constexpr int PER = NH / 2 / kThreads, G = PER < DDN_WHOLE_G ? PER : DDN_WHOLE_G;    // loads in flight per thread: 3 G
     cx<float> mid = mk<float>(0.f, 0.f);
     if (tid == 0) mid = S[sr.at(NH / 2)];
 #pragma unroll
@@ -126,7 +126,6 @@ __global__ void __launch_bounds__(kThreads) k_row_whole(WholeRowArgs a, typename
     const Tw<float> tw = tw_setup<float>(twa, a.twHalf, NH, tid, kThreads);
     const cx<float>* const wW = a.c.twW;                     // exp(-2 pi i k / W), k < W
     const bool consume = a.c.do_consume != 0, produce = a.c.do_produce != 0;
-    const int dbg = a.c.dbg_mode;   // profiling only (results are wrong): 1 skips the transforms, 2 the spectrum passes, 4 the pixel step
     const size_t nrows = (size_t)a.c.batch * a.c.H;
     for (size_t row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int plane = (int)(row / a.c.H);
@@ -137,9 +136,9 @@ __global__ void __launch_bounds__(kThreads) k_row_whole(WholeRowArgs a, typename
         asm volatile("" : "+v"(tq));
         __syncthreads();                                     // the previous row's transforms are done with the LDS
         if (consume) {
-            if (!(dbg & 2)) spectrum_to_lds<NH, kThreads>(L, a.c.S0, sr, wW, tid);
+            spectrum_to_lds<NH, kThreads>(L, a.c.S0, sr, wW, tid);
             __syncthreads();
-            if (!(dbg & 1)) fft_inverse_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+            fft_inverse_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int p0 = 2 * (tq + kThreads * c);
@@ -148,9 +147,9 @@ __global__ void __launch_bounds__(kThreads) k_row_whole(WholeRowArgs a, typename
                 left[c] = L[SW((p0 + NH - 1) & (NH - 1))].y;         // pixel 2 p0 - 1 (circular)
             }
             __syncthreads();
-            if (!(dbg & 2)) spectrum_to_lds<NH, kThreads>(L, a.c.S1, sr, wW, tid);
+            spectrum_to_lds<NH, kThreads>(L, a.c.S1, sr, wW, tid);
             __syncthreads();
-            if (!(dbg & 1)) fft_inverse_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+            fft_inverse_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
         } else {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -170,8 +169,8 @@ __global__ void __launch_bounds__(kThreads) k_row_whole(WholeRowArgs a, typename
                 ku[0] = z0.x; ku[1] = z0.y; ku[2] = z1.x; ku[3] = z1.y;
             }
             const float du[4] = {u[c][0] - left[c], u[c][1] - u[c][0], u[c][2] - u[c][1], u[c][3] - u[c][2]};
-            float re[4] = {0.f, 0.f, 0.f, 0.f}, im[4] = {0.f, 0.f, 0.f, 0.f}, s[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!(dbg & 4)) P::template step<4>(pa, consume, produce, row * (size_t)W + (size_t)(2 * p0), u[c], ku, du, re, im, s, acc);
+            float re[4], im[4], s[4];
+            P::template step<4>(pa, consume, produce, row * (size_t)W + (size_t)(2 * p0), u[c], ku, du, re, im, s, acc);
             if (produce) {
                 // the other transform input goes straight to the LDS slots this thread has just read
                 L[SW(p0)] = mk<float>(im[0], im[1]);
@@ -204,8 +203,8 @@ __global__ void __launch_bounds__(kThreads) k_row_whole(WholeRowArgs a, typename
                 if (lane == 63) r = wave < kThreads / 64 - 1 ? sfw[c * 17 + wave + 1] : sfw[((c + 1) % NC) * 17];
                 u[c][3] -= r;
             }
-            if (!(dbg & 1)) fft_forward_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
-            if (!(dbg & 2)) lds_to_spectrum<NH, kThreads>(L, a.c.S1, sr, wW, tid);
+            fft_forward_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+            lds_to_spectrum<NH, kThreads>(L, a.c.S1, sr, wW, tid);
             __syncthreads();
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -214,8 +213,119 @@ __global__ void __launch_bounds__(kThreads) k_row_whole(WholeRowArgs a, typename
                 L[SW(p0 + 1)] = mk<float>(u[c][2], u[c][3]);
             }
             __syncthreads();
-            if (!(dbg & 1)) fft_forward_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
-            if (!(dbg & 2)) lds_to_spectrum<NH, kThreads>(L, a.c.S0, sr, wW, tid);
+            fft_forward_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+            lds_to_spectrum<NH, kThreads>(L, a.c.S0, sr, wW, tid);
+        }
+    }
+}
+
+// Chambolle-Pock (chambolle_pock/algorithm.py:58-92) on the same row layout: one array each way.  STEP 0 (dual):
+// consume K z, update y (cp:60-76), produce y0.  STEP 1 (primal): consume K^T y0, update x and z (cp:79-87), produce z.
+// D z and D^T(y1 + y2) are differences of arrays the step only reads, so the neighbours of a chunk's first / last
+// pixel come from memory (circular along the row).
+template <int NH, int kThreads>
+__global__ void __launch_bounds__(kThreads) k_row_whole_cp(WholeRowArgs a, CpArgs<float> p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int W = 2 * NH, NC = W / (4 * kThreads);
+    cx<float>* const L = reinterpret_cast<cx<float>*>(smem);
+    cx<float>* const twa = L + NH;
+    double* const red = reinterpret_cast<double*>(twa + tw_lds_entries(NH));
+    const int tid = threadIdx.x;
+    const Tw<float> tw = tw_setup<float>(twa, a.twHalf, NH, tid, kThreads);
+    const cx<float>* const wW = a.c.twW;
+    const bool consume = a.c.do_consume != 0, produce = a.c.do_produce != 0;
+    const size_t nrows = (size_t)a.c.batch * a.c.H;
+    for (size_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int plane = (int)(row / a.c.H);
+        const SpecRow sr = spec_row(a.c.lay, plane, (int)(row - (size_t)plane * a.c.H));
+        const size_t ro = row * (size_t)W;
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        __syncthreads();
+        if (consume) {
+            spectrum_to_lds<NH, kThreads>(L, a.c.S0, sr, wW, tid);
+            __syncthreads();
+            fft_inverse_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+        }
+        double acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int p0 = 2 * (tq + kThreads * c), n0 = 2 * p0;
+            const size_t o = ro + n0;
+            float in[4] = {0.f, 0.f, 0.f, 0.f}, out[4];
+            if (consume) {
+                const cx<float> z0 = L[SW(p0)], z1 = L[SW(p0 + 1)];
+                in[0] = z0.x; in[1] = z0.y; in[2] = z1.x; in[3] = z1.y;
+            }
+            if (p.step == 0) {
+                float z[4], b[4], y0[4], y1[4], y2[4];
+                vload_keep<float, 4>(p.z + o, z);
+                const float zprev = p.z[ro + (n0 == 0 ? W - 1 : n0 - 1)];
+                vload_keep<float, 4>(p.b + o, b);
+                vload<float, 4>(p.y0 + o, y0);
+                vload<float, 4>(p.y1 + o, y1);
+                vload<float, 4>(p.y2 + o, y2);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float dz = z[v] - (v == 0 ? zprev : z[v - 1]);                         // cp:61
+                    const float g0 = y0[v] + p.s * in[v];                                        // cp:66
+                    const float g1 = y1[v] + p.s * dz;
+                    const float g2 = y2[v] + p.s * dz;
+                    float pr0;
+                    if (p.objective == 0) pr0 = soft(g0 / p.s - b[v], p.is); else pr0 = (g0 / p.s - b[v]) / p.l2div;   // cp:69-72
+                    const float y0n = g0 - p.s * b[v] - p.s * pr0;
+                    float i1, i2;
+                    iso(g1 / p.s, g2 / p.s, p.isg, i1, i2);                                      // cp:75
+                    y0[v] = y0n;
+                    y1[v] = g1 - p.s * i1;
+                    y2[v] = g2 - p.s * i2;
+                    out[v] = y0n;
+                }
+                vstore<float, 4>(p.y0 + o, y0);
+                vstore<float, 4>(p.y1 + o, y1);
+                vstore<float, 4>(p.y2 + o, y2);
+            } else if (consume) {
+                float x[4], b[4], y1[4], y2[4], zn[4];
+                vload<float, 4>(p.y1 + o, y1);
+                vload<float, 4>(p.y2 + o, y2);
+                const size_t on = ro + (n0 + 4 == W ? 0 : n0 + 4);
+                const float scnext = p.y1[on] + p.y2[on];
+                vload<float, 4>(p.x + o, x);
+                vload_keep<float, 4>(p.b + o, b);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float sc = y1[v] + y2[v];
+                    const float nx = v == 3 ? scnext : y1[v + 1] + y2[v + 1];
+                    const float dty = sc - nx;                                                   // D^T(y1 + y2), cp:79
+                    const float xn = clip01(x[v] - p.t * (in[v] + dty));                         // cp:83-86
+                    zn[v] = 2.f * xn - x[v];                                                     // cp:87
+                    const float d = xn - b[v];                                                   // cp:96
+                    acc[0] += (double)t_abs(d); acc[1] += (double)d * (double)d;
+                    x[v] = xn;
+                    out[v] = zn[v];
+                }
+                vstore<float, 4>(p.x + o, x);
+                vstore<float, 4>(p.z + o, zn);
+            } else {
+                vload_keep<float, 4>(p.z + o, out);
+            }
+            if (produce) {
+                L[SW(p0)] = mk<float>(out[0], out[1]);
+                L[SW(p0 + 1)] = mk<float>(out[2], out[3]);
+            }
+        }
+        if (p.step == 1 && consume) {
+            block_reduce<4>(acc, red, tid, kThreads);
+            if (tid == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a.c.partials[row * 4 + q] = acc[q];
+            }
+        }
+        if (produce) {
+            __syncthreads();
+            fft_forward_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+            lds_to_spectrum<NH, kThreads>(L, a.c.S0, sr, wW, tid);
         }
     }
 }

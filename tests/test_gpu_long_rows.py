@@ -102,10 +102,10 @@ def test_forced_split_rows_fp64_vs_oracle(pkg, golden_dir, monkeypatch):
                                         (16, 8192, "whole"), (16, 8192, "split")])
 def test_rows_and_columns_of_32768_vs_oracle(pkg, golden_dir, monkeypatch, H, W, rows):
     """The line lengths of the 32768 x 32768 configuration: 32768-row columns take the split column transform;
-    32768-, 16384- and 8192-pixel rows of the resolvent solvers run with the whole row in one workgroup's LDS
-    (csrc/ddn_wholerow.hpp), Chambolle-Pock's -- and everybody's with
-    DDN_NO_WHOLE_ROWS -- take the split row transform (8 x 4096, 4 x 4096; at 8192 pixels the workgroup-per-row LDS
-    kernel with the full-length complex transform).  All four solvers, N = 10, fp32 <= 1e-5."""
+    32768-, 16384- and 8192-pixel rows run with the whole row in one workgroup's LDS (csrc/ddn_wholerow.hpp: the
+    policy kernel of the three resolvent solvers and the Chambolle-Pock kernel); with DDN_NO_WHOLE_ROWS they take the
+    split row transform (8 x 4096, 4 x 4096; at 8192 pixels the workgroup-per-row LDS kernel with the full-length
+    complex transform).  All four solvers, N = 10, fp32 <= 1e-5."""
     if rows == "split":
         monkeypatch.setenv("DDN_NO_WHOLE_ROWS", "1")
     kern, b, stC, stA, stP = _problem(golden_dir, H, W, "motion15_45", torch.float32)

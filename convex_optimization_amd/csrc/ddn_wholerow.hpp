@@ -26,6 +26,11 @@ namespace wholerow {
 #ifndef DDN_WHOLE_SCH
 #define DDN_WHOLE_SCH 16
 #endif
+#ifndef DDN_WHOLE_MINW
+#define DDN_WHOLE_MINW 2
+#endif
+// wavefronts per SIMD the 256-thread kernels (rows of 8192 pixels, 35 KB of LDS) are compiled for: 2 = 256 registers, two rows per CU
+constexpr int kMinWaves256 = DDN_WHOLE_MINW;
 constexpr int kSch = DDN_WHOLE_SCH;   // radix schedule of the LDS transforms: 16 (four passes at 16384; measured 3 % ahead of 8, five passes)
 
 template <int NH>
@@ -115,7 +120,7 @@ __device__ __forceinline__ void lds_to_spectrum(const cx<float>* L, cx<float>* S
 }
 
 template <class P, int NH, int kThreads>
-__global__ void __launch_bounds__(kThreads) k_row_whole(WholeRowArgs a, typename P::Args pa) {
+__global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) k_row_whole(WholeRowArgs a, typename P::Args pa) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int W = 2 * NH, NC = W / (4 * kThreads);       // NC chunks of four consecutive pixels per thread
     cx<float>* const L = reinterpret_cast<cx<float>*>(smem);
@@ -224,7 +229,7 @@ __global__ void __launch_bounds__(kThreads) k_row_whole(WholeRowArgs a, typename
 // D z and D^T(y1 + y2) are differences of arrays the step only reads, so the neighbours of a chunk's first / last
 // pixel come from memory (circular along the row).
 template <int NH, int kThreads>
-__global__ void __launch_bounds__(kThreads) k_row_whole_cp(WholeRowArgs a, CpArgs<float> p) {
+__global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) k_row_whole_cp(WholeRowArgs a, CpArgs<float> p) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int W = 2 * NH, NC = W / (4 * kThreads);
     cx<float>* const L = reinterpret_cast<cx<float>*>(smem);

@@ -94,3 +94,16 @@ def test_two_waves_per_simd(kernels):
     for token in ["k_wave_rowI", "k_wave_cpI", "k_wave_rowNI", "k_wave_cpNI", "k_wave_colILi", "k_wave_colNI"]:
         for n, k in _family(kernels, token).items():
             assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 256, (n, k[".vgpr_count"], k.get(".agpr_count"))
+
+
+def test_whole_row_kernels_fit_their_occupancy(kernels):
+    """The whole-row kernels (rows of 8192 / 16384 / 32768 pixels, csrc/ddn_wholerow.hpp) are compiled for two
+    wavefronts per SIMD: at most 256 registers, or a 512-thread workgroup does not fit a compute unit and the
+    256-thread ones run one row per CU instead of two.  The policy kernels park loop-invariant addresses and part of
+    the row around the transforms (scratch outside the transform passes; bounded here), the Chambolle-Pock ones none."""
+    fam = _family(kernels, "k_row_whole")
+    assert len(fam) >= 12, sorted(fam)
+    for n, k in fam.items():
+        assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 256, (n, k[".vgpr_count"])
+        limit = 0 if "k_row_whole_cp" in n else 768
+        assert k[".private_segment_fixed_size"] <= limit, (n, k[".private_segment_fixed_size"], k.get(".vgpr_spill_count"))

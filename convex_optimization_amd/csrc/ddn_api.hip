@@ -739,6 +739,7 @@ int launch_solver_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, con
                 return whole_row_launch<P>(p->stream, p->num_cu, wa, a);
             }
         }
+        if (!p->long_R) return fail(DDN_E_STATE, "row launch: no whole-row kernel and no split for this row length");
         LongArgs<T> la;
         int rc = long_args<T>(p, c, 3, la);
         if (rc) return rc;
@@ -761,6 +762,7 @@ int launch_cp_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, const C
             }
         }
         if (p->injected) return fail(DDN_E_UNSUPPORTED, "chambolle_pock with injected eigen arrays: rows wider than 8192 pixels are not supported");
+        if (!p->long_R) return fail(DDN_E_STATE, "row launch: no whole-row kernel and no split for this row length");
         LongArgs<T> la;
         int rc = long_args<T>(p, c, 1, la);
         if (rc) return rc;

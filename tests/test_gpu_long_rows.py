@@ -112,3 +112,44 @@ def test_rows_and_columns_of_32768_vs_oracle(pkg, golden_dir, monkeypatch, H, W,
     res = _all_four(pkg, kern, b, stC, stA, stP, 10)
     bad = {k: v for k, v in res.items() if not v < 1e-5}
     assert not bad, res
+
+
+def test_early_stop_and_batch_on_whole_row_kernels(pkg, golden_dir):
+    """The per-image stop flag on the whole-row kernels (rows of 8192 pixels): primal DR stops at the oracle's
+    iteration with the oracle's iterate, and in a batch of two images each freezes at its own iteration, bit-identical
+    to the single-image runs; ADMM's look-ahead solution (admm:118-154) the same way."""
+    H, W = 16, 8192
+    k = np.load(os.path.join(golden_dir, "kernels.npz"))
+    kern = torch.from_numpy(k["gauss9"])
+    torch.manual_seed(0)
+    img = torch.rand(2, H, W)
+    b2 = O.add_gaussian_noise(O.circular_convolve2d(img, kern), 0.0, 0.05)
+    b2[1] = 0.1 * b2[1] + 0.45      # a flatter second image: its loss runs below the first one's
+    trajs = []
+    for i in range(2):
+        trajs.append([])
+        O.primal_dr_splitting("l1", kern, b2[i], niters=14, loss_function=O.mse, tol=-1.0, losses=trajs[i])
+    tol = 0.5 * (float(trajs[0][7]) + float(trajs[1][7]))
+    assert float(trajs[1][7]) < 0.97 * float(trajs[0][7])
+    counts, singles = [], []
+    for i in range(2):
+        ol = []
+        xo = O.primal_dr_splitting("l1", kern, b2[i], niters=14, loss_function=O.mse, tol=tol, losses=ol)
+        x, losses = pkg.primal_dr_splitting("l1", kern, b2[i], niters=14, loss_function=pkg.core.mse, tol=tol, return_losses=True)
+        assert len(losses) == len(ol)
+        assert rel(x.numpy(), xo.numpy()) < 1e-5
+        counts.append(len(ol)); singles.append(x)
+    assert counts[0] < 14 and counts[0] != counts[1]
+    xb = pkg.primal_dr_splitting("l1", kern, b2, niters=14, loss_function=pkg.core.mse, tol=tol)
+    for i in range(2):
+        assert np.array_equal(xb[i].numpy(), singles[i].numpy())
+    stA = tuple(torch.clamp(torch.randn(s), 0, 1) for s in [(H, W), (H, W), (3, H, W), (3, H, W)])
+    ol = []
+    O.admm_solver(b2[0], "l1", kernel=kern, niters=30, tol=-1.0, loss_function=O.mse, init_state=stA, losses=ol)
+    tolA = 0.5 * (float(ol[9]) + float(ol[10])) if ol[10] < ol[9] else None
+    if tolA is not None:
+        ol2 = []
+        xo = O.admm_solver(b2[0], "l1", kernel=kern, niters=30, tol=tolA, loss_function=O.mse, init_state=stA, losses=ol2)
+        x, losses = pkg.admm_solver(b2[0], "l1", kernel=kern, niters=30, tol=tolA, loss_function=pkg.core.mse, init_state=stA, return_losses=True)
+        assert len(losses) == len(ol2) and len(ol2) < 29
+        assert rel(x.numpy(), xo.numpy()) < 1e-5

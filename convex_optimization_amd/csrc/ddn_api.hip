@@ -539,7 +539,7 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
             if (wave1 && MODE == COL_RES2) {
                 // half of the first round starts late (k_wave_col): DDN_COL_STAGGER_US overrides the delay, 0 switches it off
                 static const double stagger_us = getenv("DDN_COL_STAGGER_US") ? atof(getenv("DDN_COL_STAGGER_US")) : kColStaggerUs;
-                w.stagger = (int)(stagger_us * 100.0);
+                w.stagger = (int)(std::min(50.0, std::max(0.0, stagger_us)) * 100.0);   // ticks of the 100 MHz wall clock; at most 50 us
                 w.stagger_blocks = p->num_cu;     // the first round: one eight-wave workgroup per compute unit
             }
             TimerScope ts(p, false);

@@ -14,7 +14,15 @@ ops = pkg.DeblurDenoiseOperators(kern, b[0], 2.0, device=dev, batch=1)
 st = [b.clone(), torch.stack((b, b, b)).contiguous()]
 lib = L.lib()
 lib.ddn_plan_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-L.check(lib.ddn_pdr_run(ops.plan._h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 2.0, 0.1, 0.049, 0, 4, 0, -1.0, 3, C.c_void_p(0), C.c_void_p(0)))
+if os.environ.get("DDN_STAMPS_SOLVER") == "cp":
+    # multiplier mode (Chambolle-Pock): four-wave workgroups, two per CU, one round
+    ops.close()
+    ops = pkg.DeblurDenoiseOperators(kern, b[0], 1, 1, device=dev, batch=1)
+    stc = [torch.rand(1, H, W, device=dev), torch.rand(1, H, W, device=dev), torch.rand(3, 1, H, W, device=dev)]
+    ring = torch.zeros((8, 1, 8), dtype=torch.float64, device=dev)
+    L.check(lib.ddn_cp_run(ops.plan._h, _ptr(stc[0]), _ptr(stc[1]), _ptr(stc[2]), _ptr(b), 0.4, 0.7, 0.01, 0, 4, _ptr(ring)))
+else:
+    L.check(lib.ddn_pdr_run(ops.plan._h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 2.0, 0.1, 0.049, 0, 4, 0, -1.0, 3, C.c_void_p(0), C.c_void_p(0)))
 torch.cuda.synchronize()
 buf = np.zeros((8192, 16), dtype=np.int64)
 L.check(lib.ddn_plan_debug_stamps(ops.plan._h, buf.ctypes.data_as(C.c_void_p), 8192))

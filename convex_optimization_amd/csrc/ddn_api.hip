@@ -1014,6 +1014,7 @@ int set_resolvent_impl(ddn_plan* p, double cK, double cD, const void* M_dev, int
         }
         p->have_G = true;
         p->g_cK = cK; p->g_cD = cD;
+        p->Gcm_ok = true;    // closed form of the plan's own eK: the register-resident column kernels recompute it
         return DDN_OK;
     }
     if (M_dev) {
@@ -1466,7 +1467,8 @@ int slab_cols_impl(ddn_plan* p, void* spec_all, int tile_lo_all, int ntiles_all,
             std::memset(&w, 0, sizeof(w));
             w.S0 = (cx<float>*)spec;
             w.S1 = (cx<float>*)spec + s1_off;
-            w.eKc = (const cx<float>*)p->eKc + (size_t)col_lo * wcol::kColPitch;
+            // a plan of ddn_plan_create_slab holds the column-major eigenvalues of its own columns only
+            w.eKc = (const cx<float>*)p->eKc + (size_t)(col_lo - (p->restricted ? (p->slab_lo << p->cs) : 0)) * wcol::kColPitch;
             w.ctab = (wave1 && p->ctab_ok) ? (const cx<float>*)p->ctab + (size_t)col_lo * 64 : nullptr;
             w.wtw = (const cx<float>*)(wave1 ? p->wtw : p->wtwH);
             w.ed2 = (const float*)p->ed2 + col_lo;
@@ -1672,6 +1674,7 @@ int ddn_slab_restrict(ddn_plan* p, int tile_lo, int n_tiles_local) {
     p->slab_lo = tile_lo;
     p->slab_n = n_tiles_local;
     p->have_K = p->have_G = false;
+    p->eKc_ok = p->Gcm_ok = p->ctab_ok = false;   // the column-major copy belongs to the previous range
     const size_t m = std::max<size_t>(1, (size_t)n_tiles_local * (((size_t)(p->H + p->tile_pad_rows)) << p->cs));
     const size_t esz = p->dtype == DDN_F32 ? sizeof(float) : sizeof(double);
     HIPCHK(hipMalloc(&p->eK, m * 2 * esz));
@@ -1732,7 +1735,31 @@ int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
         if (rcl) return rcl;
         p->have_K = true;
         p->injected = false;
-        p->eKc_ok = p->Gcm_ok = p->ctab_ok = false;      // the tile-generic column kernels only
+        p->eKc_ok = p->Gcm_ok = p->ctab_ok = false;
+        // the register-resident column kernels (H = 512 ... 4096, float) read a column-major copy of the eigenvalues:
+        // here of the plan's own columns only (ddn_slab_cols offsets into it relative to the first of them)
+        if (p->dtype == DDN_F32 && !getenv("DDN_NO_WAVE_COLS") &&
+            ((p->wtw && p->H == 4096 && p->cs == 4) || (p->wtwH && (1 << p->cs) >= 4096 / p->H && p->cs <= 4))) {
+            const int col_lo = p->slab_lo << p->cs, ncols = std::min(p->Wh - col_lo, p->slab_n << p->cs);
+            if (ncols > 0) {
+                if (p->eKc) {
+                    HIPCHK(hipStreamSynchronize(p->stream));
+                    (void)hipFree(p->eKc);
+                    p->eKc = nullptr;
+                }
+                HIPCHK(hipMalloc(&p->eKc, (size_t)wcol::kColPitch * ncols * sizeof(cx<float>)));
+                SpecLayout lay = layout_of(p);
+                lay.ntile = p->slab_n;
+                hipLaunchKernelGGL(wcol::k_mult_colmajor<float>, dim3(ew_grid((size_t)p->H * ncols)), dim3(256), 0, p->stream, (const cx<float>*)p->eK,
+                                   (const float*)nullptr, (cx<float>*)p->eKc, (float*)nullptr, p->H, ncols, lay, colmap<float>(p));
+                HIPCHK(hipGetLastError());
+                p->eKc_ok = true;
+                if (p->wtw && p->H == 4096 && p->cs == 4 && kh <= 31 && !getenv("DDN_NO_TAPS")) {
+                    int rct = make_ctab(p, taps, kh, kw);     // every column of the plane: 512 bytes each
+                    if (rct) return rct;
+                }
+            }
+        }
         return DDN_OK;
     }
     int rc = p->dtype == DDN_F32 ? set_kernel_impl<float>(p, taps, kh, kw, false, (cx<float>*)p->eK)

@@ -23,15 +23,15 @@ namespace wholerow {
 #ifndef DDN_WHOLE_G
 #define DDN_WHOLE_G 8
 #endif
-#ifndef DDN_WHOLE_SCH
-#define DDN_WHOLE_SCH 16
-#endif
-#ifndef DDN_WHOLE_MINW
-#define DDN_WHOLE_MINW 2
-#endif
 // wavefronts per SIMD the 256-thread kernels (rows of 8192 pixels, 35 KB of LDS) are compiled for: 2 = 256 registers, two rows per CU
-constexpr int kMinWaves256 = DDN_WHOLE_MINW;
-constexpr int kSch = DDN_WHOLE_SCH;   // radix schedule of the LDS transforms: 16 (four passes at 16384; measured 3 % ahead of 8, five passes)
+constexpr int kMinWaves256 = 2;
+
+// Radix schedule of the LDS transforms (ddn_fft.hpp): 16 = radix-16 passes first (four passes at 16384), 8 = radix-8 passes
+// (fewer live registers).  Measured: the policy kernels are 16 % faster with 8 at 4096 points (rows of 8192 pixels, where
+// the radix-16 butterflies spill beside the row's registers) and 3 % faster with 16 at 8192 / 16384 points; the
+// Chambolle-Pock kernels, which hold no row in registers, take 16 everywhere.
+template <int NH, bool POLICY>
+constexpr int sch_for() { return (POLICY && NH <= 4096) ? 8 : 16; }
 
 template <int NH>
 __host__ __device__ constexpr size_t lds_bytes() {
@@ -45,7 +45,7 @@ __device__ __forceinline__ cx<float> times_i(cx<float> a) { return mk<float>(-a.
 // transform starts from.  No barrier inside.  A thread owns the pairs (k, NH - k), k = tid + i kThreads < NH / 2, and
 // issues all of its global loads before the first use (a loop of load-use-load would be a chain of memory round
 // trips: 16 per pass; here groups of 24 loads); thread 0 also takes the self-paired term k = NH / 2.
-template <int NH, int kThreads>
+template <int NH, int kThreads, int kSch>
 __device__ __forceinline__ void spectrum_to_lds(cx<float>* L, const cx<float>* S, const SpecRow& sr, const cx<float>* wW, int tid) {
     // (an opaque copy of the thread index: the unrolled addresses below would otherwise be hoisted out of the row loop
     // as a hundred loop invariants and spilled)
@@ -85,7 +85,7 @@ __device__ __forceinline__ void spectrum_to_lds(cx<float>* L, const cx<float>* S
 }
 
 // Z (digit-reversed LDS positions, after the forward transform) -> half-spectrum X[0 .. NH] in global memory.
-template <int NH, int kThreads>
+template <int NH, int kThreads, int kSch>
 __device__ __forceinline__ void lds_to_spectrum(const cx<float>* L, cx<float>* S, const SpecRow& sr, const cx<float>* wW, int tid) {
     asm volatile("" : "+v"(tid));
     constexpr int PER = NH / 2 / kThreads, G = PER < DDN_WHOLE_G ? PER : DDN_WHOLE_G;
@@ -122,6 +122,7 @@ __device__ __forceinline__ void lds_to_spectrum(const cx<float>* L, cx<float>* S
 template <class P, int NH, int kThreads>
 __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) k_row_whole(WholeRowArgs a, typename P::Args pa) {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int kSch = sch_for<NH, true>();
     constexpr int W = 2 * NH, NC = W / (4 * kThreads);       // NC chunks of four consecutive pixels per thread
     cx<float>* const L = reinterpret_cast<cx<float>*>(smem);
     cx<float>* const twa = L + NH;
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
         asm volatile("" : "+v"(tq));
         __syncthreads();                                     // the previous row's transforms are done with the LDS
         if (consume) {
-            spectrum_to_lds<NH, kThreads>(L, a.c.S0, sr, wW, tid);
+            spectrum_to_lds<NH, kThreads, kSch>(L, a.c.S0, sr, wW, tid);
             __syncthreads();
             fft_inverse_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
 #pragma unroll
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
                 left[c] = L[SW((p0 + NH - 1) & (NH - 1))].y;         // pixel 2 p0 - 1 (circular)
             }
             __syncthreads();
-            spectrum_to_lds<NH, kThreads>(L, a.c.S1, sr, wW, tid);
+            spectrum_to_lds<NH, kThreads, kSch>(L, a.c.S1, sr, wW, tid);
             __syncthreads();
             fft_inverse_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
         } else {
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
                 u[c][3] -= r;
             }
             fft_forward_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
-            lds_to_spectrum<NH, kThreads>(L, a.c.S1, sr, wW, tid);
+            lds_to_spectrum<NH, kThreads, kSch>(L, a.c.S1, sr, wW, tid);
             __syncthreads();
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
             }
             __syncthreads();
             fft_forward_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
-            lds_to_spectrum<NH, kThreads>(L, a.c.S0, sr, wW, tid);
+            lds_to_spectrum<NH, kThreads, kSch>(L, a.c.S0, sr, wW, tid);
         }
     }
 }
@@ -231,6 +232,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
 template <int NH, int kThreads>
 __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) k_row_whole_cp(WholeRowArgs a, CpArgs<float> p) {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int kSch = sch_for<NH, false>();
     constexpr int W = 2 * NH, NC = W / (4 * kThreads);
     cx<float>* const L = reinterpret_cast<cx<float>*>(smem);
     cx<float>* const twa = L + NH;
@@ -248,7 +250,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
         asm volatile("" : "+v"(tq));
         __syncthreads();
         if (consume) {
-            spectrum_to_lds<NH, kThreads>(L, a.c.S0, sr, wW, tid);
+            spectrum_to_lds<NH, kThreads, kSch>(L, a.c.S0, sr, wW, tid);
             __syncthreads();
             fft_inverse_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
         }
@@ -330,7 +332,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
         if (produce) {
             __syncthreads();
             fft_forward_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
-            lds_to_spectrum<NH, kThreads>(L, a.c.S0, sr, wW, tid);
+            lds_to_spectrum<NH, kThreads, kSch>(L, a.c.S0, sr, wW, tid);
         }
     }
 }

@@ -27,11 +27,11 @@ namespace wholerow {
 constexpr int kMinWaves256 = 2;
 
 // Radix schedule of the LDS transforms (ddn_fft.hpp): 16 = radix-16 passes first (four passes at 16384), 8 = radix-8 passes
-// (fewer live registers).  Measured: the policy kernels are 16 % faster with 8 at 4096 points (rows of 8192 pixels, where
-// the radix-16 butterflies spill beside the row's registers) and 3 % faster with 16 at 8192 / 16384 points; the
+// (fewer live registers).  Measured: the policy kernels are 16-19 % faster with 8 at 4096 and 8192 points (rows of 8192 and
+// 16384 pixels, where the radix-16 butterflies spill beside the row's registers) and 1-3 % faster with 16 at 16384 points; the
 // Chambolle-Pock kernels, which hold no row in registers, take 16 everywhere.
 template <int NH, bool POLICY>
-constexpr int sch_for() { return (POLICY && NH <= 4096) ? 8 : 16; }
+constexpr int sch_for() { return (POLICY && NH <= 8192) ? 8 : 16; }
 
 template <int NH>
 __host__ __device__ constexpr size_t lds_bytes() {

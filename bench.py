@@ -81,14 +81,22 @@ def measured_traffic(lib_version, H, W, B):
     tools/tools_pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction applied).  Only figures measured on
     the library version that is running, at this problem size, are reported; otherwise null."""
     import glob
-    best = None
+    best, seen = None, []
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             rec = json.load(open(path))
         except Exception:
             continue
-        if rec.get("ddn_version") == lib_version and rec.get("size") == [H, W] and rec.get("batch") == B:
-            best = rec
+        if rec.get("size") == [H, W] and rec.get("batch") == B:
+            seen.append(rec.get("ddn_version"))
+            if rec.get("ddn_version") == lib_version:
+                best = rec
+    if best is None:
+        # no silent null: say why there is no figure
+        why = (f"no PMC record for library version {lib_version} at {H}x{W}, batch {B} under profiles/ (records of this size exist for versions "
+               f"{sorted(set(v for v in seen if v is not None))}); run tools/tools_pmc.sh on this version") if seen else \
+              f"no PMC record at {H}x{W}, batch {B} under profiles/; run tools/tools_pmc.sh"
+        return {"kernels": {}, "source": None, "missing": why}
     return best
 
 
@@ -245,7 +253,7 @@ def run_batch(args, dev, dt, rank, world, distributed, allreduce):
             if name == "chambolle_pock":
                 L.check(lib.ddn_cp_run(h, _ptr(st[0]), _ptr(st[1]), _ptr(st[2]), _ptr(b), 0.4, 0.7, 0.01, 0, n_it, _ptr(ring)))
             elif name == "primal_dr_splitting":
-                L.check(lib.ddn_pdr_run(h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 2.0, 0.1, 0.049, 0, n_it, L.LOSS_MSE, -1.0, 3, _ptr(ring), _ptr(done)))
+                L.check(lib.ddn_pdr_run(h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 2.0, 0.1, 0.049, L.OBJ_DUALS_EQUAL, n_it, L.LOSS_MSE, -1.0, 3, _ptr(ring), _ptr(done)))
             elif name == "primal_dual_dr_splitting":
                 L.check(lib.ddn_pddr_run(h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 3.0, 0.4, 0.03, n_it, L.LOSS_L2, -1.0, 2, _ptr(ring), _ptr(done)))
             else:
@@ -463,7 +471,7 @@ def main():
             ops = pkg.DeblurDenoiseOperators(kern, b[0], 2.0, device=dev, batch=B, dtype=dt, tune=tune)
             st = [b.clone(), torch.stack((b, b, b)).contiguous()]
             def run(n, ring, st=st, ops=ops):
-                L.check(lib.ddn_pdr_run(ops.plan._h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 2.0, 0.1, 0.049, 0, n, L.LOSS_MSE, -1.0, 3, _ptr(ring), _ptr(done)))
+                L.check(lib.ddn_pdr_run(ops.plan._h, _ptr(st[0]), _ptr(st[1]), _ptr(b), 2.0, 0.1, 0.049, L.OBJ_DUALS_EQUAL, n, L.LOSS_MSE, -1.0, 3, _ptr(ring), _ptr(done)))
         elif name == "primal_dual_dr_splitting":
             ops = pkg.DeblurDenoiseOperators(kern, b[0], 3, 3, device=dev, batch=B, dtype=dt, tune=tune)
             st = [rnd(B, H, W), rnd(3, B, H, W)]
@@ -549,7 +557,7 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         domk = kernels[dom]
         roof = {"bound": "hbm", "achieved": domk["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": domk["frac"],
-                "traffic": domk["traffic"], "traffic_source": (pmc or {}).get("source"), "kernel": dom,
+                "traffic": domk["traffic"], "traffic_source": (pmc or {}).get("source") or (pmc or {}).get("missing"), "kernel": dom,
                 "algorithmic_bytes_per_launch": domk["algorithmic_bytes"], "kernel_ms": domk["ms"]}
     else:
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": None}

@@ -12,6 +12,7 @@ _LIB_PATH = os.environ.get("DDN_LIB_PATH") or os.path.join(_HERE, "libddn.so")
 F32, F64 = 0, 1
 C64, C128 = 0, 1
 OBJ = {"l1": 0, "l2": 1}
+OBJ_DUALS_EQUAL = 0x100   # ddn_pdr_run: the two difference duals start equal (ddn.h)
 LOSS_NONE, LOSS_L1, LOSS_L2, LOSS_MSE, LOSS_PSNR, LOSS_SSIM = 0, 1, 2, 3, 4, 5
 OP_K, OP_KT, OP_D, OP_DT, OP_RESOLVENT, OP_MAT = 0, 1, 2, 3, 4, 5
 PROX_L1, PROX_L2SQ, PROX_ISO, PROX_BOX, PROX_L2 = 0, 1, 2, 3, 4
@@ -46,6 +47,7 @@ def lib():
         "ddn_plan_set_resolvent": [vp, d, d, vp, i],
         "ddn_plan_get_eigK": [vp, vp],
         "ddn_plan_set_ssim": [vp, C.POINTER(C.c_float), d, vp],
+        "ddn_plan_set_ssim_cadence": [vp, i],
         "ddn_apply": [vp, i, vp, vp],
         "ddn_apply_multiplier": [vp, vp, i, i, vp, vp],
         "ddn_circular_convolve2d": [vp, C.POINTER(d), i, i, vp, vp],
@@ -53,6 +55,7 @@ def lib():
         "ddn_reduce": [i, vp, vp, sz, i, vp, vp],
         "ddn_reduce_static": [i, vp, vp, sz, i, vp, vp],
         "ddn_ssim": [i, vp, vp, i, i, i, d, C.POINTER(C.c_float), vp, vp],
+        "ddn_ssim_window": [i, vp, vp, i, i, i, d, C.POINTER(C.c_float), i, vp, vp],
         "ddn_apply_x_trans": [i, vp, vp, i, vp, vp],
         "ddn_cp_run": [vp, vp, vp, vp, vp, d, d, d, i, i, vp],
         "ddn_admm_run": [vp, vp, vp, vp, vp, vp, d, d, d, i, i, i, d, i, vp, vp, vp],
@@ -91,7 +94,7 @@ def check(rc: int):
 
 
 EXPORTED = ["ddn_version", "ddn_last_error", "ddn_plan_create", "ddn_plan_destroy", "ddn_plan_set_stream", "ddn_plan_tune",
-            "ddn_plan_set_kernel", "ddn_plan_set_eig", "ddn_plan_set_resolvent", "ddn_plan_set_ssim", "ddn_plan_get_eigK", "ddn_apply",
-            "ddn_apply_multiplier", "ddn_circular_convolve2d", "ddn_prox", "ddn_reduce", "ddn_reduce_static", "ddn_ssim", "ddn_apply_x_trans", "ddn_cp_run", "ddn_admm_run",
+            "ddn_plan_set_kernel", "ddn_plan_set_eig", "ddn_plan_set_resolvent", "ddn_plan_set_ssim", "ddn_plan_set_ssim_cadence", "ddn_plan_get_eigK", "ddn_apply",
+            "ddn_apply_multiplier", "ddn_circular_convolve2d", "ddn_prox", "ddn_reduce", "ddn_reduce_static", "ddn_ssim", "ddn_ssim_window", "ddn_apply_x_trans", "ddn_cp_run", "ddn_admm_run",
             "ddn_pdr_run", "ddn_pddr_run", "ddn_plan_last_timing", "ddn_plan_enable_timing", "ddn_plan_debug_stamps",
             "ddn_slab_layout", "ddn_slab_cols_part", "ddn_plan_create_slab", "ddn_slab_restrict", "ddn_slab_rows", "ddn_slab_cols", "ddn_slab_loss", "ddn_slab_begin", "ddn_slab_loss_sums", "ddn_slab_stop_test", "ddn_slab_iters_done", "ddn_slab_rows_cp", "ddn_slab_cols_multiply"]

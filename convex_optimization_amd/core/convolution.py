@@ -4,7 +4,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from ..plan import Plan, compute_device, real_dtype, stage
+from ..plan import create_plan, compute_device, real_dtype, stage
 
 
 def circular_convolve2d(image, kernel, **kwargs):
@@ -19,7 +19,7 @@ def circular_convolve2d(image, kernel, **kwargs):
     dt = real_dtype(kwargs.get("dtype", image.dtype))
     dev = compute_device(kwargs.get("device", src))
     Cn, H, W = image.shape
-    plan = Plan(H, W, Cn, dt, dev)
+    plan = create_plan(H, W, Cn, dt, dev)
     try:
         out = plan.circular_convolve2d(kernel, stage(image, dev, dt))
         torch.cuda.synchronize(dev)

@@ -51,24 +51,27 @@ mse._ddn_kind = L.LOSS_MSE
 psnr._ddn_kind = L.LOSS_PSNR
 
 
-def ssim_window_taps() -> torch.Tensor:
-    """The 11 normalised float32 factors of the reference's Gaussian window (loss.py:75-81), evaluated with the same
+def ssim_window_taps(window_size: int = 11) -> torch.Tensor:
+    """The normalised float32 factors of the reference's Gaussian window (loss.py:75-81), evaluated with the same
     torch expression so that they agree bit for bit."""
-    co = torch.arange(11, dtype=torch.float32) - 11 // 2
+    co = torch.arange(window_size, dtype=torch.float32) - window_size // 2
     g = torch.exp(-(co ** 2) / (2 * 1.5 ** 2))
     return (g / g.sum()).contiguous()
 
 
 def ssim(x: torch.Tensor, y: torch.Tensor, window_size: int = 11, max_val: float = 1.0) -> torch.Tensor:
-    """SSIM with an 11x11 Gaussian (sigma 1.5) window and zero padding (loss.py:39-110): one fused pass over the two
-    images on the GPU (ddn_ssim).  Inputs on the host are staged to the device; the result returns where x lives."""
+    """SSIM with a Gaussian (sigma 1.5) window and zero padding (loss.py:39-110): one fused pass over the two images on
+    the GPU for the default 11 x 11 window (ddn_ssim), direct evaluation of the taps for any other window_size
+    (ddn_ssim_window; an even size gives a map one row and one column larger than the image, as in the reference).
+    Inputs on the host are staged to the device; the result returns where x lives."""
     def to4(t):
         return t[None, None] if t.dim() == 2 else (t[None] if t.dim() == 3 else t)
     x, y = to4(x), to4(y)
     if x.shape != y.shape:
         raise ValueError(f"Input tensors must have the same shape, got {x.shape} and {y.shape}")
-    if window_size != 11:
-        raise L.DdnError("ssim: the fused kernel implements the reference's default 11 x 11 window only")
+    window_size = int(window_size)
+    if window_size < 1:
+        raise ValueError(f"window_size must be positive, got {window_size}")
     import ctypes as C
     from ..plan import _ptr
     src = x.device
@@ -78,10 +81,14 @@ def ssim(x: torch.Tensor, y: torch.Tensor, window_size: int = 11, max_val: float
     xc = x.detach().to(device=dev, dtype=dt).contiguous()
     yc = y.detach().to(device=dev, dtype=dt).contiguous()
     out = torch.empty((B * nc,), dtype=torch.float64, device=dev)
-    g11 = (C.c_float * 11)(*ssim_window_taps().tolist())
+    g = (C.c_float * window_size)(*ssim_window_taps(window_size).tolist())
     with torch.cuda.device(dev):
-        L.check(L.lib().ddn_ssim(L.F64 if dt == torch.float64 else L.F32, _ptr(xc), _ptr(yc), H, W, B * nc, float(max_val), g11, _ptr(out),
-                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if window_size == 11:
+            L.check(L.lib().ddn_ssim(L.F64 if dt == torch.float64 else L.F32, _ptr(xc), _ptr(yc), H, W, B * nc, float(max_val), g, _ptr(out), st))
+        else:
+            L.check(L.lib().ddn_ssim_window(L.F64 if dt == torch.float64 else L.F32, _ptr(xc), _ptr(yc), H, W, B * nc, float(max_val), g, window_size,
+                                            _ptr(out), st))
     return out.view(B, nc).mean(dim=1).to(device=src, dtype=dt)
 
 

@@ -40,7 +40,7 @@ namespace {
 
 
 // ------------------------------------------------------------------------------ factorisation
-constexpr int kMaxPrimeRadix = 509;
+constexpr int kMaxPrimeRadix = 2039;   // largest prime below 2 x 1024 threads (see fft_min_threads)
 
 bool factorize(int n, FftDesc& d) {
     std::memset(&d, 0, sizeof(d));
@@ -86,7 +86,8 @@ bool factorize(int n, FftDesc& d) {
             rem /= p;
         }
     }
-    // larger prime factors (17 .. kMaxPrimeRadix): the runtime-radix pass of ddn_fft.hpp (O(p) work per element)
+    // larger prime factors (17 .. kMaxPrimeRadix): the runtime-radix pass of ddn_fft.hpp (O(p) work per element; a fallback that
+    // makes such sizes run, not a fast path)
     for (int q = 17; q <= kMaxPrimeRadix && rem > 1; q += 2) {
         while (rem % q == 0) {
             rad.push_back(q);
@@ -128,6 +129,15 @@ bool factorize(int n, FftDesc& d) {
         for (int s = 0; s < d.npass; ++s) d.rshift[s] = 0;
     }
     return true;
+}
+
+// The runtime-radix pass of ddn_fft.hpp (prime factors above 13) evaluates at most two outputs per thread and round,
+// and a round is at least one whole butterfly: a workgroup that runs a pass of radix r needs 2 * threads >= r.
+int fft_min_threads(const FftDesc& d) {
+    int m = 64;
+    for (int s = 0; s < d.npass; ++s)
+        if (d.radix[s] > 16) m = std::max(m, ((d.radix[s] + 1) / 2 + 63) / 64 * 64);
+    return m;
 }
 
 template <typename T>
@@ -189,6 +199,7 @@ struct ddn_plan {
     float ssim_g[11] = {};
     double ssim_max = 1.0;
     double* ssim_ring = nullptr;   // caller-owned [iter][image][2]; null = off
+    int ssim_b_every = 50;         // primal DR: ssim(z1, b) is recorded at iterations 1, 1 + n, 1 + 2 n, ... (the reference's logging cadence)
     double* ssim_part = nullptr;   // per-tile partial sums
     double* ssim_val = nullptr;    // [batch]
     void* ssim_prev = nullptr;     // copy of the previous iterate (primal DR compares z1 with z1prev)
@@ -198,8 +209,23 @@ struct ddn_plan {
     void* twL = nullptr;       // its twiddle table
     void* twHalf = nullptr;    // twiddle table of length W / 2 for the whole-row kernels (W = 8192 / 16384 / 32768, float), or null
     void* edL = nullptr;       // analytic row-spectral D, eD[k] = 1 - w_W^k, k <= W/2
-    void* Ylong = nullptr;     // [3][rows][R/2 + 1][M] complex, sized for Ylong_rows rows
+    void* Ylong = nullptr;     // [Ylong_narr][rows][R/2 + 1][M] complex, sized for Ylong_rows rows
     size_t Ylong_rows = 0;
+    // path switches for A/B measurements and tests, read from the environment ONCE, at plan creation (a launch costs no
+    // getenv, and a plan keeps the paths it was built for even if the process changes the environment afterwards)
+    struct Env {
+        bool no_wave_cols = false, no_wave_rows = false, force_wave_rows = false, no_whole_rows = false, no_ilv = false,
+             no_nyq_dense = false, no_nyq_fir = false, no_pdr_twin = false, no_taps = false;
+        int debug_mode = 0;
+        void read() {
+            auto on = [](const char* n) { return getenv(n) != nullptr; };
+            no_wave_cols = on("DDN_NO_WAVE_COLS"); no_wave_rows = on("DDN_NO_WAVE_ROWS"); force_wave_rows = on("DDN_FORCE_WAVE_ROWS");
+            no_whole_rows = on("DDN_NO_WHOLE_ROWS"); no_ilv = on("DDN_NO_ILV"); no_nyq_dense = on("DDN_NO_NYQ_DENSE");
+            no_nyq_fir = on("DDN_NO_NYQ_FIR"); no_pdr_twin = on("DDN_NO_PDR_TWIN"); no_taps = on("DDN_NO_TAPS");
+            debug_mode = getenv("DDN_DEBUG_MODE") ? atoi(getenv("DDN_DEBUG_MODE")) : 0;
+        }
+    } env;
+    int Ylong_narr = 0;        // arrays it holds (1: Chambolle-Pock and plain transforms, 3: the resolvent solvers)
     void* nyq_taps = nullptr;  // blur taps transformed along the rows at column W/2 (real, kh entries): see RowCommon::nyq_taps
     int nyq_kh = 0, nyq_ph = 0;
     bool nyq_fir_on = false;   // a Chambolle-Pock loop runs with column W/2 handled by the row kernels
@@ -485,21 +511,22 @@ int launch_col_one(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t 
     return launch_col_fn<T, MODE, 0>(p, a, nblocks, threads, lds);
 }
 
-inline int col_threads_for(const ddn_plan* p, int n, int cs, int narr) {
+inline int col_threads_for(const ddn_plan* p, const FftDesc& fd, int cs, int narr) {
+    const int n = fd.n;
     int threads = std::min(1024, std::max(64, (((n << cs) * narr) / 16 + 63) / 64 * 64));
     if (p->col_threads > 0) threads = std::max(64, std::min(1024, p->col_threads / 64 * 64));
-    return threads;
+    return std::max(threads, fft_min_threads(fd));
 }
 
 inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
 
 constexpr double kColStaggerUs = 8.0;   // default delay of the late half of the column stage's first round
 inline bool wcol_ready(const ddn_plan* p) {
-    return p->eKc_ok && p->wtw && p->H == 4096 && p->cs == 4 && !p->injected && !p->slab_cols && !getenv("DDN_NO_WAVE_COLS");
+    return p->eKc_ok && p->wtw && p->H == 4096 && p->cs == 4 && !p->injected && !p->slab_cols && !p->env.no_wave_cols;
 }
 // H = 512 / 1024 / 2048: several adjacent columns per wavefront (ddn_wcoln.hpp)
 inline bool wcoln_ready(const ddn_plan* p) {
-    return p->eKc_ok && p->wtwH && (1 << p->cs) >= 4096 / p->H && p->cs <= 4 && !p->injected && !p->slab_cols && !getenv("DDN_NO_WAVE_COLS");
+    return p->eKc_ok && p->wtwH && (1 << p->cs) >= 4096 / p->H && p->cs <= 4 && !p->injected && !p->slab_cols && !p->env.no_wave_cols;
 }
 // column-major natural-order copy of a tiled multiplier (complex and / or real)
 template <typename T>
@@ -575,7 +602,7 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
         a.nseg = 1; a.row_stride = 1; a.seg_stride = 0;
         a.outer = 0;
         a.lf = lf;
-        return launch_col_one<T, MODE>(p, a, nplanes * a.lay.ntile, col_threads_for(p, a.fd.n, cs, NARR), col_lds_bytes<T>(a.fd.n, cs, NARR));
+        return launch_col_one<T, MODE>(p, a, nplanes * a.lay.ntile, col_threads_for(p, a.fd, cs, NARR), col_lds_bytes<T>(a.fd.n, cs, NARR));
     }
     // split transform: strided length-A stage, middle length-B stage (with the pointwise algebra),
     // strided length-A inverse stage
@@ -585,7 +612,7 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
     s.nseg = p->B; s.row_stride = p->B; s.seg_stride = 1;
     s.outer = 0;
     s.scale = (T)1;
-    const int thr_s = col_threads_for(p, p->A, cs, NARR);
+    const int thr_s = col_threads_for(p, p->fa, cs, NARR);
     const size_t lds_s = col_lds_bytes<T>(p->A, cs, NARR);
     const int nb_s = nplanes * s.nseg * s.lay.ntile;
     int rc;
@@ -603,7 +630,7 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
     a.nseg = p->A; a.row_stride = 1; a.seg_stride = p->B;
     a.outer = (MODE == COL_FWD) ? 1 : 3;
     a.lf.stop = lf.stop; a.lf.iter = lf.iter;
-    if ((rc = launch_col_one<T, MODE>(p, a, nplanes * a.nseg * a.lay.ntile, col_threads_for(p, a.fd.n, cs, NARR), col_lds_bytes<T>(a.fd.n, cs, NARR)))) return rc;
+    if ((rc = launch_col_one<T, MODE>(p, a, nplanes * a.nseg * a.lay.ntile, col_threads_for(p, a.fd, cs, NARR), col_lds_bytes<T>(a.fd.n, cs, NARR)))) return rc;
     if (MODE == COL_FWD) return DDN_OK;
     // inverse short stage
     s.dir = 1;
@@ -633,36 +660,37 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
     // (half for Chambolle-Pock, whose wavefronts carry twice the rows) the workgroup-per-row LDS kernels
     // finish sooner (measured at 512 x 512 and 1024 x 1024, one to four images).  DDN_FORCE_WAVE_ROWS=1 overrides.
     const int wave_items = (W == 4096) ? work_items : p->batch * p->H / ((cp ? 2 : 1) * std::max(1, 4096 / W));
-    const bool wave_pays = wave_items > (cp ? p->num_cu / 2 : p->num_cu / 4) || getenv("DDN_FORCE_WAVE_ROWS");
-    if (sizeof(T) == 4 && p->wtwW && !p->injected && p->H % ((cp ? 2 : 1) * (4096 / W)) == 0 && wave_pays && !getenv("DDN_NO_WAVE_ROWS")) {
+    const bool wave_pays = wave_items > (cp ? p->num_cu / 2 : p->num_cu / 4) || p->env.force_wave_rows;
+    if (sizeof(T) == 4 && p->wtwW && !p->injected && p->H % ((cp ? 2 : 1) * (4096 / W)) == 0 && wave_pays && !p->env.no_wave_rows) {
         // one wavefront per 4096 / W consecutive rows, twice as many for Chambolle-Pock (ddn_wrown.hpp)
         rc.V = 0; rc.threads = 64; rc.lds = 0;
         const int items = p->batch * p->H / ((cp ? 2 : 1) * (4096 / W));
         rc.grid = std::max(1, std::min(items, p->num_cu * 8));
         return true;
     }
-    if (sizeof(T) == 4 && p->wtw && W == 4096 && p->cs == 4 && !p->injected && wave_pays && !getenv("DDN_NO_WAVE_ROWS")) {
+    if (sizeof(T) == 4 && p->wtw && W == 4096 && p->cs == 4 && !p->injected && wave_pays && !p->env.no_wave_rows) {
         // one wavefront per row, eight per CU (256 registers each), the row held in registers
         rc.V = 0; rc.threads = 64; rc.lds = 0;
         rc.grid = std::max(1, std::min(work_items, p->num_cu * 8));
         return true;
     }
-    if (sizeof(T) == 4 && p->twHalf && !p->injected && aligned && !getenv("DDN_NO_WHOLE_ROWS")) {
+    if (sizeof(T) == 4 && p->twHalf && !p->injected && aligned && !p->env.no_whole_rows) {
         // 8192-pixel rows: the whole-row kernel (ddn_wholerow.hpp) instead of scalar accesses
         // and the run-time transform below; V = -1 is resolved in launch_solver_row
         rc.V = -1; rc.threads = 256; rc.lds = 0; rc.grid = 1; rc.aligned = aligned;
         return true;
     }
-    if (aligned && W % 4 == 0 && W <= 4096) {
+    if (aligned && W % 4 == 0 && W <= 4096 && fft_min_threads(p->fw) <= 256) {   // (256: the launch bound of the V = 4 kernels)
         rc.V = 4;
         // float kernels specialised for these widths use eight pixels per thread (W/8 threads, radix-8
         // passes); every other V = 4 kernel sixteen pixels per thread (W/16 threads)
         const bool eight = sizeof(T) == 4 && !p->injected && (W == 512 || W == 1024 || W == 2048 || W == 4096);
         rc.threads = eight ? W / 8 : std::min(256, std::max(64, (W / 16 + 63) / 64 * 64));
+        if (!eight) rc.threads = std::max(rc.threads, fft_min_threads(p->fw));   // at most 256: within the kernels' launch bound
     } else {
         if (W > 8192) return false;
         rc.V = 1;
-        rc.threads = std::min(1024, std::max(64, ((W + 7) / 8 + 63) / 64 * 64));
+        rc.threads = std::max(std::min(1024, std::max(64, ((W + 7) / 8 + 63) / 64 * 64)), fft_min_threads(p->fw));
     }
     rc.lds = row_lds_bytes<T>(W, rc.V);
     if (rc.lds > kLdsMax) return false;
@@ -693,7 +721,7 @@ RowCommon<T> row_common(ddn_plan* p, int V, bool consume, bool produce) {
     c.do_consume = consume ? 1 : 0;
     c.do_produce = produce ? 1 : 0;
     c.dbg = p->dbg;
-    c.dbg_mode = getenv("DDN_DEBUG_MODE") ? atoi(getenv("DDN_DEBUG_MODE")) : 0;
+    c.dbg_mode = p->env.debug_mode;
     return c;
 }
 
@@ -703,14 +731,15 @@ inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 template <typename T>
 int long_args(ddn_plan* p, const RowCommon<T>& c, int narr, LongArgs<T>& a) {
     const size_t rows = (size_t)c.batch * c.H;
-    if (rows > p->Ylong_rows) {
+    if (rows * narr > p->Ylong_rows * p->Ylong_narr) {
         if (p->Ylong) {
             HIPCHK(hipStreamSynchronize(p->stream));
             (void)hipFree(p->Ylong);
             p->Ylong = nullptr;
         }
-        HIPCHK(hipMalloc(&p->Ylong, 3 * rows * (size_t)(p->long_R / 2 + 1) * p->long_M * sizeof(cx<T>)));
+        HIPCHK(hipMalloc(&p->Ylong, (size_t)narr * rows * (size_t)(p->long_R / 2 + 1) * p->long_M * sizeof(cx<T>)));
         p->Ylong_rows = rows;
+        p->Ylong_narr = narr;
     }
     std::memset(&a, 0, sizeof(a));
     a.c = c;
@@ -718,7 +747,7 @@ int long_args(ddn_plan* p, const RowCommon<T>& c, int narr, LongArgs<T>& a) {
     a.twM = (const cx<T>*)p->twL;
     a.ed = p->injected ? (const cx<T>*)p->eDrow : (const cx<T>*)p->edL;
     a.fm = p->fl;
-    a.wtw = getenv("DDN_NO_WAVE_ROWS") ? nullptr : (const cx<float>*)p->wtw;
+    a.wtw = p->env.no_wave_rows ? nullptr : (const cx<float>*)p->wtw;
     a.R = p->long_R; a.M = p->long_M;
     a.narr = narr;
     return DDN_OK;
@@ -732,7 +761,7 @@ int launch_solver_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, con
     if (cfg.V == -1) {
         if constexpr (sizeof(T) == 4) {
             // rows of 16384 / 32768 pixels with the two-tap D: the row in one workgroup's LDS (ddn_wholerow.hpp)
-            if (p->twHalf && !p->injected && cfg.aligned && !getenv("DDN_NO_WHOLE_ROWS")) {
+            if (p->twHalf && !p->injected && cfg.aligned && !p->env.no_whole_rows) {
                 WholeRowArgs wa;
                 wa.c = c;
                 wa.twHalf = (const cx<float>*)p->twHalf;
@@ -754,18 +783,25 @@ int launch_cp_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, const C
     TimerScope ts(p, true, c.do_consume && c.do_produce);
     if (cfg.V == -1) {
         if constexpr (sizeof(T) == 4) {
-            if (p->twHalf && !p->injected && cfg.aligned && !getenv("DDN_NO_WHOLE_ROWS")) {
+            if (p->twHalf && !p->injected && cfg.aligned && !p->env.no_whole_rows) {
                 WholeRowArgs wa;
                 wa.c = c;
                 wa.twHalf = (const cx<float>*)p->twHalf;
                 return whole_row_cp_launch(p->stream, p->num_cu, wa, a);
             }
         }
-        if (p->injected) return fail(DDN_E_UNSUPPORTED, "chambolle_pock with injected eigen arrays: rows wider than 8192 pixels are not supported");
         if (!p->long_R) return fail(DDN_E_STATE, "row launch: no whole-row kernel and no split for this row length");
         LongArgs<T> la;
-        int rc = long_args<T>(p, c, 1, la);
+        // injected eigen arrays: D z and D^T(y1 + y2) as a second spectrum in S1 (LongArgs::cp_spec), two arrays in the dual step
+        const bool spec = p->injected;
+        int rc = long_args<T>(p, c, spec && a.step == 0 ? 2 : 1, la);
         if (rc) return rc;
+        if (spec) {
+            la.cp_spec = 1;
+            la.inv_add_s1 = a.step == 1 ? 1 : 0;
+            la.fwd_mode = a.step == 1 ? 1 : 2;
+            la.wtw = nullptr;        // the frequency-side kernels with these modes are the generic ones
+        }
         return long_cp_launch<T>(p->stream, p->num_cu, la, a);
     }
     return cp_launch<T>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.V, c, a);
@@ -829,7 +865,7 @@ int rows_r2c(ddn_plan* p, const T* src, int nplanes) {
     auto fn = k_rows_r2c<T>;
     int rc;
     if ((rc = ensure_lds_attr((const void*)fn))) return rc;
-    const int threads = std::min(1024, std::max(64, (p->W / 8 + 63) / 64 * 64));
+    const int threads = std::max(std::min(1024, std::max(64, (p->W / 8 + 63) / 64 * 64)), fft_min_threads(p->fw));
     const int pairs = nplanes * ((p->H + 1) / 2);
     hipLaunchKernelGGL(fn, dim3(std::min(pairs, p->num_cu * 4)), dim3(threads), lds, p->stream, a);
     HIPCHK(hipGetLastError());
@@ -855,7 +891,7 @@ int rows_c2r(ddn_plan* p, T* dst, int nplanes, T scale, const T* add) {
     auto fn = k_rows_c2r<T>;
     int rc;
     if ((rc = ensure_lds_attr((const void*)fn))) return rc;
-    const int threads = std::min(1024, std::max(64, (p->W / 8 + 63) / 64 * 64));
+    const int threads = std::max(std::min(1024, std::max(64, (p->W / 8 + 63) / 64 * 64)), fft_min_threads(p->fw));
     const int pairs = nplanes * ((p->H + 1) / 2);
     hipLaunchKernelGGL(fn, dim3(std::min(pairs, p->num_cu * 4)), dim3(threads), lds, p->stream, a);
     HIPCHK(hipGetLastError());
@@ -1093,8 +1129,8 @@ struct NyqDense {
         p->ilv_on = false;
         if (!wave_rows) return;
         // both stages on the wave kernels: interleave the two half-spectra (not with 4-column tiles)
-        p->ilv_on = res2 && (wcol_ready(p) || wcoln_ready(p)) && p->cs > 2 && p->Gcm_ok && !getenv("DDN_NO_ILV");
-        if (p->W != 4096 || !wcol_ready(p) || p->W % 2 || (p->Wh & 3) != 1 || getenv("DDN_NO_NYQ_DENSE")) return;
+        p->ilv_on = res2 && (wcol_ready(p) || wcoln_ready(p)) && p->cs > 2 && p->Gcm_ok && !p->env.no_ilv;
+        if (p->W != 4096 || !wcol_ready(p) || p->W % 2 || (p->Wh & 3) != 1 || p->env.no_nyq_dense) return;
         if (!p->nyqd && hipMalloc(&p->nyqd, sizeof(float) * 2 * (size_t)p->batch * p->H) != hipSuccess) { p->nyqd = nullptr; return; }
         p->nyqd_on = true;
     }
@@ -1132,6 +1168,8 @@ int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, doubl
     RowCommon<T> rc0;
     std::memset(&a, 0, sizeof(a));
     a.z1 = (T*)z1; a.z20 = (T*)z2; a.z21 = (T*)z2 + plane; a.z22 = (T*)z2 + 2 * plane; a.b = (const T*)b;
+    const bool duals_equal = (objective & DDN_OBJ_DUALS_EQUAL) != 0;
+    objective &= ~DDN_OBJ_DUALS_EQUAL;
     a.t = (T)t; a.rho = (T)rho; a.tg = (T)(t * gamma); a.l2div = (T)(2 * t + 1); a.objective = objective;
     int rc;
     if ((rc = need_ssim(p, tol_kind))) return rc;
@@ -1144,17 +1182,10 @@ int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, doubl
     // reference starts both from b (pdr:88-89) and updates them by the same expression of the same inputs.  The run then
     // points both kernel arguments at z21: every second access hits the line the first one brought in (or merges with
     // its store), so one array's worth of reads and of writes never reaches memory, and z22 is brought up to date by one
-    // copy at the end.  One comparison pass and one copy per run, so only runs of some length take it.
-    bool twin = false;
-    if (n_iters >= 8 && !getenv("DDN_NO_PDR_TWIN")) {
-        int same = 1;
-        HIPCHK(hipMemcpyAsync(p->stop_scratch(), &same, sizeof(int), hipMemcpyHostToDevice, p->stream));
-        hipLaunchKernelGGL(k_same_bits<T>, dim3(ew_grid(plane)), dim3(256), 0, p->stream, (const T*)a.z21, (const T*)a.z22, plane, p->stop_scratch());
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&same, p->stop_scratch(), sizeof(int), hipMemcpyDeviceToHost, p->stream));
-        HIPCHK(hipStreamSynchronize(p->stream));
-        twin = same != 0;
-    }
+    // copy at the end.  One copy per run, so only runs of some length take it.
+    // The caller states that they start equal (DDN_OBJ_DUALS_EQUAL in `objective`): nothing is compared here, and the
+    // call stays free of host round trips.
+    const bool twin = n_iters >= 8 && duals_equal && !p->env.no_pdr_twin;
     struct TwinBack {   // z22 <- z21 when the run ends, however it ends
         ddn_plan* p; void* dst; const void* src; size_t bytes; bool on;
         ~TwinBack() { if (on) (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, p->stream); }
@@ -1169,11 +1200,10 @@ int pdr_run_impl(ddn_plan* p, void* z1, void* z2, const void* b, double t, doubl
             if (ssim) HIPCHK(hipMemcpyAsync(p->ssim_prev, z1, plane * sizeof(T), hipMemcpyDeviceToDevice, p->stream));
             rc0 = row_common<T>(p, cfg.V, true, c < n_iters);
             if ((rc = launch_solver_row<T, PdrP<T>>(p, cfg, rc0, a))) return rc;
-            if (ssim) {
-                if ((rc = ssim_step<T>(p, z1, p->ssim_prev, c, 0, 0, first_loss_iter, tol, true))) return rc;
-                // the reference logs loss_function(z1, b) every 50th iteration (pdr:137-141)
-                if ((c - 1) % 50 == 0 && (rc = ssim_step<T>(p, z1, b, c, 1, 0, 0, 0.0, false))) return rc;
-            }
+            if (ssim && (rc = ssim_step<T>(p, z1, p->ssim_prev, c, 0, 0, first_loss_iter, tol, true))) return rc;
+            // ssim(z1, b): the reference logs it every 50th iteration (pdr:137-141) and records it at every iteration when it
+            // saves the loss history (pdr:146-154); the cadence is the plan's (ddn_plan_set_ssim_cadence)
+            if (p->ssim_ring && (c - 1) % p->ssim_b_every == 0 && (rc = ssim_step<T>(p, z1, b, c, 1, 0, 0, 0.0, false))) return rc;
         }
         if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, lk, tol, first_loss_iter, true)))) return rc;
     }
@@ -1208,7 +1238,7 @@ int pddr_run_impl(ddn_plan* p, void* pp, void* q, const void* b, double t, doubl
             if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
             rc0 = row_common<T>(p, cfg.V, true, c < n_iters);
             if ((rc = launch_solver_row<T, PddrP<T>>(p, cfg, rc0, a))) return rc;
-            if (ssim && (rc = ssim_step<T>(p, pp, b, c, 0, 1, first_loss_iter, tol, true))) return rc;   // loss(clip(p), b), pddr:104
+            if (p->ssim_ring && (rc = ssim_step<T>(p, pp, b, c, 0, 1, first_loss_iter, tol, ssim))) return rc;   // loss(clip(p), b), pddr:104
         }
         if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, lk, tol, first_loss_iter, true)))) return rc;
     }
@@ -1249,10 +1279,10 @@ int admm_run_impl(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b
         LossFin lf = make_lf(p, ring, c - 2, lk, tol, first_loss_iter, true);
         if ((rc = col_stage<T, COL_RES2>(p, p->batch, (const cx<T>*)p->eK, (const T*)p->G, gc, 0, (T)1, lf))) return rc;
         rc0 = row_common<T>(p, cfg.V, true, true);
-        a.sol = (tol_kind > 0) ? (T*)sol : nullptr;
+        a.sol = (tol_kind > 0 || p->ssim_ring) ? (T*)sol : nullptr;
         if ((rc = launch_solver_row<T, AdmmP<T>>(p, cfg, rc0, a))) return rc;
         // launch c stored the look-ahead solution of iteration c - 1 (admm:118-139)
-        if (ssim && (rc = ssim_step<T>(p, sol, b, c - 1, 0, 0, first_loss_iter, tol, true))) return rc;
+        if (p->ssim_ring && (rc = ssim_step<T>(p, sol, b, c - 1, 0, 0, first_loss_iter, tol, ssim))) return rc;
     }
     {
         LossFin lf = make_lf(p, ring, n_iters - 1, lk, tol, first_loss_iter, true);
@@ -1261,7 +1291,7 @@ int admm_run_impl(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b
         a.sol = (T*)sol; a.sol_only = 1;
         if ((rc = launch_solver_row<T, AdmmP<T>>(p, cfg, rc0, a))) return rc;
         if (n_iters >= 1) {
-            if (ssim && (rc = ssim_step<T>(p, sol, b, n_iters, 0, 0, first_loss_iter, tol, true))) return rc;
+            if (p->ssim_ring && (rc = ssim_step<T>(p, sol, b, n_iters, 0, 0, first_loss_iter, tol, ssim))) return rc;
             if ((rc = launch_finalize<T>(p, make_lf(p, ring, n_iters, lk, tol, first_loss_iter, true)))) return rc;
         }
     }
@@ -1282,7 +1312,7 @@ int cp_run_impl(ddn_plan* p, void* x, void* z, void* y, const void* b, double t,
         ddn_plan* p;
         ~FirGuard() { p->nyq_fir_on = false; }
     } fir_guard{p};
-    p->nyq_fir_on = p->nyqd_on && p->ctab_ok && p->nyq_taps && p->nyq_kh <= 32 && sizeof(T) == 4 && !getenv("DDN_NO_NYQ_FIR");
+    p->nyq_fir_on = p->nyqd_on && p->ctab_ok && p->nyq_taps && p->nyq_kh <= 32 && sizeof(T) == 4 && !p->env.no_nyq_fir;
     int flip = 0;
     auto with_fir = [&](RowCommon<T>& rc_, int dir) {
         if (!p->nyq_fir_on) return;
@@ -1604,7 +1634,7 @@ int static_scratch(double** out) {
 // =============================================================================== C ABI
 extern "C" {
 
-int ddn_version(void) { return 240; }
+int ddn_version(void) { return 300; }
 const char* ddn_last_error(void) { return ddn_err().c_str(); }
 
 static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, void* stream, bool restricted) {
@@ -1615,12 +1645,13 @@ static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, 
     p->H = H; p->W = W; p->batch = batch; p->dtype = dtype; p->stream = (hipStream_t)stream;
     p->Wh = W / 2 + 1;
     p->restricted = restricted;
+    p->env.read();
     (void)hipGetDevice(&p->device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->num_cu = prop.multiProcessorCount;
     if (!factorize(W, p->fw) || !factorize(H, p->fh)) {
         delete p;
-        return fail(DDN_E_UNSUPPORTED, "plan_create: image size has a prime factor > 509");
+        return fail(DDN_E_UNSUPPORTED, "plan_create: image size has a prime factor > 2039");
     }
     const bool ok = dtype == DDN_F32 ? choose_col<float>(p) : choose_col<double>(p);
     if (!ok) {
@@ -1634,7 +1665,7 @@ static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, 
         const int forced = getenv("DDN_FORCE_LONG_ROWS") ? atoi(getenv("DDN_FORCE_LONG_ROWS")) : 0;   // 2, 4, 8, 16: that split; else the smallest
         for (int R : {2, 4, 8, 16}) {
             if (forced >= 2 && R != forced) continue;
-            if (W % R == 0 && W / R <= 4096 && W / R >= 2 && factorize(W / R, p->fl)) {
+            if (W % R == 0 && W / R <= 4096 && W / R >= 2 && factorize(W / R, p->fl) && fft_min_threads(p->fl) <= 256) {   // (the split-row kernels run 256 threads)
                 p->long_R = R;
                 p->long_M = W / R;
                 break;
@@ -1738,7 +1769,7 @@ int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
         p->eKc_ok = p->Gcm_ok = p->ctab_ok = false;
         // the register-resident column kernels (H = 512 ... 4096, float) read a column-major copy of the eigenvalues:
         // here of the plan's own columns only (ddn_slab_cols offsets into it relative to the first of them)
-        if (p->dtype == DDN_F32 && !getenv("DDN_NO_WAVE_COLS") &&
+        if (p->dtype == DDN_F32 && !p->env.no_wave_cols &&
             ((p->wtw && p->H == 4096 && p->cs == 4) || (p->wtwH && (1 << p->cs) >= 4096 / p->H && p->cs <= 4))) {
             const int col_lo = p->slab_lo << p->cs, ncols = std::min(p->Wh - col_lo, p->slab_n << p->cs);
             if (ncols > 0) {
@@ -1754,7 +1785,7 @@ int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
                                    (const float*)nullptr, (cx<float>*)p->eKc, (float*)nullptr, p->H, ncols, lay, colmap<float>(p));
                 HIPCHK(hipGetLastError());
                 p->eKc_ok = true;
-                if (p->wtw && p->H == 4096 && p->cs == 4 && kh <= 31 && !getenv("DDN_NO_TAPS")) {
+                if (p->wtw && p->H == 4096 && p->cs == 4 && kh <= 31 && !p->env.no_taps) {
                     int rct = make_ctab(p, taps, kh, kw);     // every column of the plane: 512 bytes each
                     if (rct) return rct;
                 }
@@ -1769,7 +1800,7 @@ int ddn_plan_set_kernel(ddn_plan* p, const double* taps, int kh, int kw) {
     p->injected = false;
     p->eKc_ok = p->Gcm_ok = false;
     p->ctab_ok = false;
-    if (p->dtype == DDN_F32 && p->wtw && p->H == 4096 && p->cs == 4 && kh <= 31 && !getenv("DDN_NO_TAPS")) {
+    if (p->dtype == DDN_F32 && p->wtw && p->H == 4096 && p->cs == 4 && kh <= 31 && !p->env.no_taps) {
         if ((rc = make_ctab(p, taps, kh, kw))) return rc;
     }
     if (p->dtype == DDN_F32 && ((p->wtw && p->H == 4096 && p->cs == 4) || (p->wtwH && (1 << p->cs) >= 4096 / p->H && p->cs <= 4))) {
@@ -1838,6 +1869,12 @@ int ddn_plan_set_ssim(ddn_plan* p, const float* g11_host, double max_val, double
     for (int i = 0; i < 11; ++i) p->ssim_g[i] = g11_host[i];
     p->ssim_max = max_val;
     p->ssim_ring = ssim_ring_dev;
+    return DDN_OK;
+}
+
+int ddn_plan_set_ssim_cadence(ddn_plan* p, int every) {
+    if (!p || every < 1) return fail(DDN_E_ARG, "set_ssim_cadence: bad arguments");
+    p->ssim_b_every = every;
     return DDN_OK;
 }
 

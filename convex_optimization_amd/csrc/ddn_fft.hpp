@@ -294,7 +294,9 @@ __device__ __forceinline__ void butterfly(cx<T>* lds, const Tw<T>& tw, int n, in
 // Pass s with a radix known only at run time (prime factors above 13): one thread per OUTPUT element, direct
 // evaluation of its r-term sum from LDS.  A butterfly's outputs overwrite its own inputs only, so the pass goes in
 // rounds over whole butterflies: compute up to KREG outputs per thread into registers, barrier, store, barrier.
-// Every thread of the workgroup must call it (it contains barriers).
+// Every thread of the workgroup must call it (it contains barriers).  A round is at least one whole butterfly, so
+// the launch must provide KREG * nt >= r threads-times-registers (the host's fft_min_threads() sizes workgroups for
+// it): with fewer, outputs tid + i * nt >= KREG * nt of a butterfly would never be computed.
 template <typename T, bool INV>
 __device__ __forceinline__ void prime_pass(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
     constexpr int KREG = 2;

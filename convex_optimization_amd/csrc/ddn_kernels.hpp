@@ -507,7 +507,7 @@ __host__ __device__ inline size_t row_lds_bytes(int W, int V) {
 template <typename T>
 struct PdrP {
     struct Args {
-        T* __restrict__ z1; T* __restrict__ z20; T* __restrict__ z21; T* __restrict__ z22;
+        T* __restrict__ z1; T* __restrict__ z20; T* z21; T* z22;   // z21 and z22 may be ONE array (equal duals: ddn_pdr_run)
         const T* __restrict__ b;
         T t, rho, tg, l2div;  // tg = t*gamma, l2div = 2t + 1
         int objective;
@@ -1350,17 +1350,6 @@ __global__ void k_export_full(const cx<T>* half, cx<T>* out, int H, int W, SpecL
             out[i] = cconj(half[spec_row(lay, 0, colpos_of_freq(cm, m1)).at(W - k2)]);
         }
     }
-}
-
-// flag[0] <- 0 when two arrays differ in any bit pattern (flag preset to 1 by the caller)
-template <typename T>
-__global__ void k_same_bits(const T* x, const T* y, size_t n, int* flag) {
-    using U = typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned>::type;
-    const U* a = reinterpret_cast<const U*>(x);
-    const U* b = reinterpret_cast<const U*>(y);
-    bool same = true;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) same = same && a[i] == b[i];
-    if (!same) flag[0] = 0;     // every writer stores the same value
 }
 
 static __global__ void k_iters_done(const int* stop, int* out, int n, int n_iters) {

@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256) k_long_inv(LongArgs<T> a) {
             const int k = R * kap + q;
             const int kk = k <= W / 2 ? k : W - k;
             cx<T> z = src[sr.at(kk)];
+            if (a.inv_add_s1) z = z + a.c.S1[sr.at(kk)];
             if (arr == 2) z = z * a.ed[kk];
             if (kk == 0 || 2 * kk == W) z.y = (T)0;          // mean and Nyquist term of a real row are real
             if (k > W / 2) z = cconj(z);
@@ -106,11 +107,14 @@ __global__ void __launch_bounds__(256) k_long_fwd(LongArgs<T> a) {
         if (a.c.stop && a.c.stop[plane] >= 0) continue;
         const SpecRow sr = spec_row(a.c.lay, plane, (int)(row - (size_t)plane * a.c.H));
         // passes: (array, destination, mode) with mode 0 store, 1 store times conj(eD), 2 add
-        const int npass = a.narr == 3 ? 3 : 1;
+        // further modes (Chambolle-Pock with a row-spectral D, LongArgs::fwd_mode): 3 store and also S1 = z eD / W,
+        // 4 store times conj(eD) / W
+        const int npass = a.narr == 3 ? 3 : (a.fwd_mode == 2 ? 2 : 1);
+        const T invW = (T)1 / (T)W;
         for (int ps = 0; ps < npass; ++ps) {
-            const int arr = a.narr == 3 ? (ps == 0 ? 2 : (ps == 1 ? 0 : 1)) : 0;
-            const int mode = a.narr == 3 ? (ps == 0 ? 1 : (ps == 1 ? 2 : 0)) : 0;
-            cx<T>* const dst = (a.narr == 3 && ps == 2) ? a.c.S1 : a.c.S0;
+            const int arr = a.narr == 3 ? (ps == 0 ? 2 : (ps == 1 ? 0 : 1)) : ps;
+            const int mode = a.narr == 3 ? (ps == 0 ? 1 : (ps == 1 ? 2 : 0)) : (a.fwd_mode == 1 ? 3 : (a.fwd_mode == 2 && ps == 1 ? 4 : 0));
+            cx<T>* const dst = ((a.narr == 3 && ps == 2) || mode == 4) ? a.c.S1 : a.c.S0;
             const cx<T>* const y = a.Y + y_index(a, arr, row, q, 0);
             __syncthreads();
             for (int m = tid; m < M; m += nt) L.data[SW(m)] = y[m];
@@ -127,6 +131,8 @@ __global__ void __launch_bounds__(256) k_long_fwd(LongArgs<T> a) {
                 const size_t o = sr.at(k);
                 if (mode == 1) z = mulc(z, a.ed[k]);
                 if (mode == 2) z = z + dst[o];
+                if (mode == 3) a.c.S1[o] = (z * a.ed[k]) * invW;
+                if (mode == 4) z = mulc(z, a.ed[k]) * invW;
                 dst[o] = z;
             }
         }
@@ -256,17 +262,19 @@ __global__ void __launch_bounds__(256) k_long_cp(LongArgs<T> a, CpArgs<T> p) {
         for (int m = tid; m < M; m += nt) {
             cx<T> twd[R / 2 + 1];
             twiddles<T, R>(a, m, twd);
-            T in[R], out[R];
+            T in[R], out[R], in1[R], out1[R];     // in1 / out1: D z in, y1 + y2 out (row-spectral D only)
 #pragma unroll
-            for (int j = 0; j < R; ++j) in[j] = (T)0;
+            for (int j = 0; j < R; ++j) in[j] = in1[j] = out1[j] = (T)0;
             if (a.c.do_consume) to_pixels<T, R>(a, 0, row, m, twd, in);
+            if (a.cp_spec && a.c.do_consume && p.step == 0) to_pixels<T, R>(a, 1, row, m, twd, in1);
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 const int n = M * j + m;
                 const size_t o = ro + n;
                 if (p.step == 0) {
-                    const T z = p.z[o], zp = p.z[ro + (n == 0 ? W - 1 : n - 1)];
-                    const T dz = z - zp;                                                      // cp:61
+                    T dz;                                                                     // cp:61
+                    if (a.cp_spec) dz = in1[j];
+                    else dz = p.z[o] - p.z[ro + (n == 0 ? W - 1 : n - 1)];
                     const T b = p.b[o];
                     const T g0 = p.y0[o] + p.s * in[j];                                       // cp:66
                     const T g1 = p.y1[o] + p.s * dz;
@@ -277,12 +285,17 @@ __global__ void __launch_bounds__(256) k_long_cp(LongArgs<T> a, CpArgs<T> p) {
                     T i1, i2;
                     iso(g1 / p.s, g2 / p.s, p.isg, i1, i2);                                   // cp:75
                     p.y0[o] = y0n;
-                    p.y1[o] = g1 - p.s * i1;
-                    p.y2[o] = g2 - p.s * i2;
+                    const T y1n = g1 - p.s * i1, y2n = g2 - p.s * i2;
+                    p.y1[o] = y1n;
+                    p.y2[o] = y2n;
                     out[j] = y0n;
+                    out1[j] = y1n + y2n;
                 } else if (a.c.do_consume) {
-                    const size_t on = ro + (n + 1 == W ? 0 : n + 1);
-                    const T dty = (p.y1[o] + p.y2[o]) - (p.y1[on] + p.y2[on]);                // D^T(y1 + y2), cp:79
+                    T dty = (T)0;                                                             // D^T(y1 + y2), cp:79 (row-spectral D: already inside `in`)
+                    if (!a.cp_spec) {
+                        const size_t on = ro + (n + 1 == W ? 0 : n + 1);
+                        dty = (p.y1[o] + p.y2[o]) - (p.y1[on] + p.y2[on]);
+                    }
                     const T x = p.x[o];
                     const T xn = clip01(x - p.t * (in[j] + dty));                             // cp:83-86
                     const T zn = (T)2 * xn - x;                                               // cp:87
@@ -296,6 +309,7 @@ __global__ void __launch_bounds__(256) k_long_cp(LongArgs<T> a, CpArgs<T> p) {
                 }
             }
             if (a.c.do_produce) from_pixels<T, R>(a, 0, row, m, twd, out);
+            if (a.cp_spec && a.c.do_produce && p.step == 0) from_pixels<T, R>(a, 1, row, m, twd, out1);
         }
         if (p.step == 1 && a.c.do_consume) {
             block_reduce<4>(acc, red, tid, nt);

@@ -16,6 +16,12 @@ struct LongArgs {
     int R, M;
     int vec;             // pixels per access of the pixel kernels: 1, or 4 when every array is 16-byte aligned and W % 4 == 0
     int narr;            // arrays crossing per direction: 3 (u, K u, D u) / (re, im, s) for the resolvent solvers, 1 otherwise
+    // Chambolle-Pock with a row-spectral D (injected eigen arrays): D z and D^T(y1 + y2) cross the row transform as a second
+    // spectrum in S1 that bypasses the column stage (hence the factor 1/W), as in k_cp_row<SPEC>:
+    int cp_spec;         //   the pixel kernel takes D z from array 1 (dual step) and hands y1 + y2 on as array 1
+    int inv_add_s1;      //   k_long_inv: array 0 = S0 + S1 (primal step: K^T y0 + D^T(y1 + y2))
+    int fwd_mode;        //   k_long_fwd: 0 plain; 1: S0 = F(a0) and S1 = eD F(a0) / W (primal step: z and D z);
+                         //   2: S0 = F(a0), S1 = conj(eD) F(a1) / W (dual step: y0 and D^T(y1 + y2))
 };
 
 template <typename T, class P>

@@ -4,6 +4,8 @@
 // images in LDS, runs the horizontal taps of the five maps into LDS, then the vertical taps per output
 // pixel, and sums the map in double.  The window is separable (the reference builds it as an outer
 // product); per image the partial sums are reduced in a fixed order by a second kernel.
+#include <algorithm>
+
 #include "ddn_launch.hpp"
 
 namespace {
@@ -111,6 +113,48 @@ __global__ void __launch_bounds__(256) k_ssim_tile(const T* x, const T* y, int H
     if (tid == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// Any window size (the reference's `window_size` argument, core/loss.py:39,75-81): direct evaluation of the
+// ws x ws taps float32(g[u] g[v]) under zero padding ws / 2, one thread per entry of the map -- which has
+// H + 2 (ws / 2) - ws + 1 rows, that is H + 1 for an even window, as the reference's conv2d calls produce.
+// Sums in double; not a performance path (the solvers' loops use the 11-tap kernel above).
+constexpr int kMaxWin = 63;
+struct SsimWinAny {
+    float g[kMaxWin];
+    int ws;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) k_ssim_any(const T* x, const T* y, int H, int W, int OH, int OW, SsimWinAny win, double c1, double c2, double* partial, int per_plane) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.x / per_plane, blk = blockIdx.x - plane * per_plane;
+    const T* xp = x + (size_t)plane * H * W;
+    const T* yp = y + (size_t)plane * H * W;
+    const int ws = win.ws, pad = ws / 2;
+    double acc = 0;
+    for (size_t i = (size_t)blk * 256 + tid; i < (size_t)OH * OW; i += (size_t)per_plane * 256) {
+        const int orow = (int)(i / OW), oc = (int)(i - (size_t)orow * OW);
+        double m[5] = {0, 0, 0, 0, 0};
+        for (int u = 0; u < ws; ++u) {
+            const int r = orow + u - pad;
+            if (r < 0 || r >= H) continue;
+            for (int v = 0; v < ws; ++v) {
+                const int c = oc + v - pad;
+                if (c < 0 || c >= W) continue;
+                const double g = (double)(win.g[u] * win.g[v]);       // the float32 product, as g[:, None] * g[None, :]
+                const double vx = (double)xp[(size_t)r * W + c], vy = (double)yp[(size_t)r * W + c];
+                m[0] += g * vx; m[1] += g * vy; m[2] += g * (vx * vx); m[3] += g * (vy * vy); m[4] += g * (vx * vy);
+            }
+        }
+        const double mux = m[0], muy = m[1];
+        const double vx = m[2] - mux * mux, vy = m[3] - muy * muy, cxy = m[4] - mux * muy;
+        acc += ((2 * mux * muy + c1) * (2 * cxy + c2)) / ((mux * mux + muy * muy + c1) * (vx + vy + c2));
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 __global__ void k_ssim_final(const double* partial, int per_plane, double npix, double* out, int out_stride) {
     __shared__ double red[256];
     const int plane = blockIdx.x, tid = threadIdx.x;
@@ -212,6 +256,32 @@ extern "C" int ddn_ssim(int dtype, const void* x, const void* y, int H, int W, i
     const hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(part);
     if (rc) return rc;
+    if (e != hipSuccess) return fail(DDN_E_HIP, hipGetErrorString(e));
+    return DDN_OK;
+}
+
+extern "C" int ddn_ssim_window(int dtype, const void* x, const void* y, int H, int W, int planes, double max_val, const float* g_host, int window_size,
+                               double* out_dev, void* stream) {
+    if (!x || !y || !out_dev || !g_host || H < 1 || W < 1 || planes < 1 || window_size < 1) return fail(DDN_E_ARG, "ssim_window: bad arguments");
+    if (window_size > kMaxWin) return fail(DDN_E_UNSUPPORTED, "ssim_window: windows of more than 63 taps are not supported");
+    hipStream_t st = (hipStream_t)stream;
+    SsimWinAny win;
+    win.ws = window_size;
+    for (int i = 0; i < kMaxWin; ++i) win.g[i] = i < window_size ? g_host[i] : 0.f;
+    const int OH = H + 2 * (window_size / 2) - window_size + 1, OW = W + 2 * (window_size / 2) - window_size + 1;
+    const int per_plane = (int)std::min<size_t>(1024, ((size_t)OH * OW + 255) / 256);
+    double* part = nullptr;
+    HIPCHK(hipMalloc((void**)&part, sizeof(double) * (size_t)per_plane * planes));
+    const double c1 = (0.01 * max_val) * (0.01 * max_val), c2 = (0.03 * max_val) * (0.03 * max_val);
+    if (dtype == DDN_F32)
+        hipLaunchKernelGGL(k_ssim_any<float>, dim3(per_plane * planes), dim3(256), 0, st, (const float*)x, (const float*)y, H, W, OH, OW, win, c1, c2, part, per_plane);
+    else
+        hipLaunchKernelGGL(k_ssim_any<double>, dim3(per_plane * planes), dim3(256), 0, st, (const double*)x, (const double*)y, H, W, OH, OW, win, c1, c2, part, per_plane);
+    hipLaunchKernelGGL(k_ssim_final, dim3(planes), dim3(256), 0, st, part, per_plane, (double)OH * (double)OW, out_dev, 1);
+    const hipError_t le = hipGetLastError();
+    const hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(part);
+    if (le != hipSuccess) return fail(DDN_E_HIP, hipGetErrorString(le));
     if (e != hipSuccess) return fail(DDN_E_HIP, hipGetErrorString(e));
     return DDN_OK;
 }

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
-from ..plan import Plan, acquire_plan, compute_device, plan_key, real_dtype, release_plan, stage
+from ..plan import Plan, clear_plan_cache, create_plan, acquire_plan, compute_device, plan_key, real_dtype, release_plan, stage
 
 
 def _ctype(dt):
@@ -29,7 +29,7 @@ def eig_vals_for_periodic_conv_op(filter_kernel, num_rows: int, num_cols: int, *
     dt = real_dtype(kwargs.get("dtype", torch.float32))
     dev = compute_device(kwargs.get("device"))
     out_dev = kwargs.get("device", "cpu")
-    plan = Plan(num_rows, num_cols, 1, dt, dev)
+    plan = create_plan(num_rows, num_cols, 1, dt, dev)
     try:
         plan.set_kernel(filter_kernel)
         e = plan.get_eigK()
@@ -57,7 +57,7 @@ def apply_periodic_conv_2d(x: torch.Tensor, eig_val_arr: torch.Tensor, **kwargs)
     if not e.is_complex():
         e = torch.complex(e, torch.zeros_like(e))
     e_rot = e * torch.tensor(-1j, dtype=e.dtype, device=e.device)
-    plan = Plan(H, W, 1, dt, dev)
+    plan = create_plan(H, W, 1, dt, dev)
     try:
         def both(v):
             vd = stage(v, dev, dt).reshape(1, H, W)
@@ -104,9 +104,22 @@ class DeblurDenoiseOperators:
             key = plan_key(self.num_rows, self.num_cols, self._batch, self._dt, self._dev, kernel, cK, cK + float(self.t) * float(self.s), kwargs.get("tune"))
         self.plan = acquire_plan(key) if key is not None else None
         if self.plan is None:
-            self.plan = Plan(self.num_rows, self.num_cols, self._batch, self._dt, self._dev, tune=kwargs.get("tune"))
-            self.plan.cache_key = key
-            self.setup_operators()
+            def build():
+                self.plan = create_plan(self.num_rows, self.num_cols, self._batch, self._dt, self._dev, tune=kwargs.get("tune"))
+                self.plan.cache_key = key
+                self.setup_operators()
+            try:
+                build()
+            except L.DdnError as e:
+                # out of device memory while plans released earlier are still parked: give their memory back, once
+                if "memory" not in str(e).lower():
+                    raise
+                if self.plan is not None:
+                    self.plan.close()
+                    self.plan = None
+                clear_plan_cache()
+                torch.cuda.empty_cache()
+                build()
 
     # mm:48-72
     def setup_operators(self):
@@ -129,7 +142,7 @@ class DeblurDenoiseOperators:
         if self._batch == 1:
             return self.plan
         if self._plan1 is None:
-            self._plan1 = Plan(self.num_rows, self.num_cols, 1, self._dt, self._dev)
+            self._plan1 = create_plan(self.num_rows, self.num_cols, 1, self._dt, self._dev)
             ea = self._eig_arrays
             cK = float(self.t) ** 2
             cD = cK + float(self.t) * float(self.s)

@@ -209,10 +209,34 @@ def _cache_capacity() -> int:
         return 2
 
 
+# Environment switches that decide how the library builds a plan (it reads them once, at plan creation): a plan built
+# under one setting must not be handed to a caller that runs under another, so they are part of the key.
+_BUILD_SWITCHES = ("DDN_FORCE_LONG_ROWS", "DDN_NO_WAVE_COLS", "DDN_NO_WAVE_ROWS", "DDN_FORCE_WAVE_ROWS", "DDN_NO_WHOLE_ROWS", "DDN_NO_ILV",
+                   "DDN_NO_NYQ_DENSE", "DDN_NO_NYQ_FIR", "DDN_NO_PDR_TWIN", "DDN_NO_TAPS", "DDN_NO_FIXED_COLS", "DDN_TILE_PAD_ROWS",
+                   "DDN_DEBUG_MODE", "DDN_DEBUG_STAMPS", "DDN_COL_STAGGER_US", "DDN_COLN_NP")
+
+
 def plan_key(H, W, batch, dtype, dev, kernel, cK, cD, tune):
     k = taps_array(kernel)
     tk = tuple(sorted((tune or {}).items()))
-    return (int(H), int(W), int(batch), str(dtype), str(dev), k.shape, k.tobytes(), float(cK), float(cD), tk)
+    env = tuple((n, os.environ[n]) for n in _BUILD_SWITCHES if n in os.environ)
+    return (int(H), int(W), int(batch), str(dtype), str(dev), k.shape, k.tobytes(), float(cK), float(cD), tk, env)
+
+
+def _parked_bytes_limit() -> int:
+    """Device memory the parked plans of one process may hold together (DDN_PLAN_CACHE_GIB, default 8 GiB): a plan of a
+    16384 x 16384 or 32768 x 32768 image holds tens of GiB and is not worth keeping for a caller that may never return."""
+    try:
+        return int(float(os.environ.get("DDN_PLAN_CACHE_GIB", "8")) * (1 << 30))
+    except ValueError:
+        return 8 << 30
+
+
+def plan_device_bytes(plan: "Plan") -> int:
+    """Estimate of the device memory a whole-plane plan owns: two half-spectra, the tiled and column-major multipliers,
+    the resolvent and scratch multipliers -- about 10 real words per pixel and image (split-row scratch not included)."""
+    word = 8 if plan.dtype == torch.float64 else 4
+    return int(10 * word * plan.H * plan.W * max(1, plan.batch))
 
 
 def acquire_plan(key):
@@ -231,10 +255,26 @@ def release_plan(plan: "Plan"):
     old = _PLAN_CACHE.pop(plan.cache_key, None)
     if old is not None and old is not plan:
         old.close()
+    limit = _parked_bytes_limit()
+    if plan_device_bytes(plan) > limit:
+        plan.close()
+        return
     _PLAN_CACHE[plan.cache_key] = plan
-    while len(_PLAN_CACHE) > cap:
+    while len(_PLAN_CACHE) > cap or sum(plan_device_bytes(q) for q in _PLAN_CACHE.values()) > limit:
         _, victim = _PLAN_CACHE.popitem(last=False)
         victim.close()
+
+
+def create_plan(*args, **kwargs) -> "Plan":
+    """Plan(...) that, when the device is out of memory, frees the parked plans and tries once more."""
+    try:
+        return Plan(*args, **kwargs)
+    except L.DdnError as e:
+        if not _PLAN_CACHE or "memory" not in str(e).lower():
+            raise
+        clear_plan_cache()
+        torch.cuda.empty_cache()
+        return Plan(*args, **kwargs)
 
 
 def clear_plan_cache():

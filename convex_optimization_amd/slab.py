@@ -234,7 +234,7 @@ class SlabSolver:
     def __init__(self, kernel, image_shape: Tuple[int, int], t_resolvent: float, s_resolvent: float, dtype=torch.float32, device=None, group=None,
                  n_spectra: int = 2, eig_arrays=None, local_multipliers: bool = True, force_exchange: bool = False, exchange_groups: int = 0):
         from . import _lib as L
-        from .plan import Plan, compute_device, real_dtype
+        from .plan import create_plan, compute_device, real_dtype
         self.L = L
         self.group = group
         self.rank, self.world = _world(group)
@@ -245,7 +245,7 @@ class SlabSolver:
         # a rank keeps the multipliers of its own spectral tiles only; injected eigen arrays (the fp64 parity route)
         # and local_multipliers=False take a plan with the whole plane, as a single-device solve has
         self.local = bool(local_multipliers) and not self.injected
-        self.plan = Plan(H, W, 1, self.dt, self.dev, slab=self.local)
+        self.plan = create_plan(H, W, 1, self.dt, self.dev, slab=self.local)
         c, n = C.c_int(0), C.c_int(0)
         L.check(L.lib().ddn_slab_layout(self.plan._h, C.byref(c), C.byref(n)))
         self.lay = SlabLayout(H, W, c.value, n.value, self.rank, self.world)

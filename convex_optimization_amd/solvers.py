@@ -14,8 +14,9 @@ exactly as B (B*C) calls of the reference would, inside one launch sequence; the
 shape, `return_losses` then gives one list per plane (a plane that stopped early has a shorter list), and the
 progress log lines describe plane 0.
 Loss functions: l1_loss, l2_loss, mse, psnr and ssim of this package are evaluated on the device inside the fused
-loop (no host round trip per iteration, early stop included); any other callable, and save_loss=True, take the
-per-iteration host loop the reference has.
+loop (no host round trip per iteration, early stop included), and with save_loss=True the five metric columns of the
+reference's CSV come from the same device records (one ddn_*_run call for the whole solve); any other callable takes
+the per-iteration host loop the reference has.
 """
 from __future__ import annotations
 
@@ -76,26 +77,41 @@ def _loss_lists(vals: torch.Tensor, done, lo: int, had_batch: bool):
 
 
 class _SsimRing:
-    """The device record of the in-loop ssim (ddn_plan_set_ssim) for one fused run; switched off again on exit."""
+    """The device record of the in-loop ssim (ddn_plan_set_ssim) for one fused run; switched off again on exit.
+    It is on when ssim is the loss, and when the metric history is wanted (record=True: save_loss); b_every is the
+    cadence of primal DR's ssim(z1, b) (1 = every iteration, the saved history; None = the library's default)."""
 
-    def __init__(self, plan, kind, n, B, dev):
-        self.plan, self.on = plan, kind == L.LOSS_SSIM
+    def __init__(self, plan, kind, n, B, dev, record=False, b_every=None):
+        self.plan, self.kind, self.on = plan, kind, (kind == L.LOSS_SSIM or record)
+        self.b_every = b_every
         self.ring = torch.full((max(n, 1), B, 2), float("nan"), dtype=torch.float64, device=dev) if self.on else None
 
     def __enter__(self):
         if self.on:
             self.plan.set_ssim(self.ring)
+            if self.b_every is not None:
+                L.check(L.lib().ddn_plan_set_ssim_cadence(self.plan._h, int(self.b_every)))
         return self
 
     def __exit__(self, *exc):
         if self.on:
             self.plan.set_ssim(None)
+            if self.b_every is not None:
+                L.check(L.lib().ddn_plan_set_ssim_cadence(self.plan._h, 50))
         return False
 
     def values(self, ring, kind, pair=0):
-        if self.on:
+        if kind == L.LOSS_SSIM:
             return self.ring[:, :, pair].cpu()
         return _ring_values(ring, kind, pair)
+
+    def metric_lists(self, ring, pair, ssim_entry, lo, hi):
+        """The five metric columns of the reference's saved history (psnr, ssim, mse, l1_loss, l2_loss of (iterate, b),
+        image 0; cp:101-107, admm:142-147, pdr:146-154, pddr:108-113) for ring rows lo .. hi - 1."""
+        r = ring[lo:hi, 0].cpu()
+        sv = self.ring[lo:hi, 0, ssim_entry].cpu()
+        cols = {"psnr": r[:, 4 * pair + 3], "ssim": sv, "mse": r[:, 4 * pair + 2], "l1_loss": r[:, 4 * pair + 0], "l2_loss": r[:, 4 * pair + 1]}
+        return {k: [float(v) for v in cols[k]] for k in ("psnr", "ssim", "mse", "l1_loss", "l2_loss")}
 
 
 def _loss_kind(loss_function) -> int:
@@ -148,12 +164,14 @@ def chambolle_pock(b: torch.Tensor, kernel: torch.Tensor, objective_function: st
         extra = {}
         with torch.cuda.device(dev):
             ops.plan.sync_stream()
-            if kind and not save_loss:
+            if kind:
                 ring = torch.zeros((max(n, 1), B, 8), dtype=torch.float64, device=dev)
-                with _SsimRing(ops.plan, kind, n, B, dev) as sr:
+                with _SsimRing(ops.plan, kind, n, B, dev, record=save_loss) as sr:
                     L.check(L.lib().ddn_cp_run(ops.plan._h, _ptr(x), _ptr(z), _ptr(y), _ptr(bd), float(t), float(s), float(gamma),
                                                L.OBJ[objective_function], n, _ptr(ring)))
                     vals = sr.values(ring, kind)
+                    if save_loss:
+                        extra = sr.metric_lists(ring, 0, 0, 1, n)                                    # (x_next, b), cp:101-107
                 losses = _loss_lists(vals, [n] * B, 1, B > 1)                                        # loss for k > 1 (cp:94)
                 first = losses[0] if B > 1 else losses
                 for k in range(2, n + 1):
@@ -179,7 +197,7 @@ def chambolle_pock(b: torch.Tensor, kernel: torch.Tensor, objective_function: st
             params = {"t": t, "gamma": gamma, "s": s, "niters": max_iter, "objective_function": objective_function,
                       "loss_function": _loss_name(loss_function)}
             params.update(extra)
-            save_loss_data(losses, "chambolle_pock", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
+            save_loss_data(losses[0] if (kind and B > 1) else losses, "chambolle_pock", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
         out = x.to(src)                                                                             # the reference broadcasts (H,W) b to (1,H,W) at cp:83
         if lead is not None:
             out = _shape_out(out, True, lead)
@@ -235,14 +253,16 @@ def admm_solver(b: torch.Tensor, objective_function: str = "l1", t: float = 18, 
         obj = L.OBJ[objective_function]
         with torch.cuda.device(dev):
             ops.plan.sync_stream()
-            if (kind or loss_function is None) and not save_loss:
+            if kind or (loss_function is None and not save_loss):
                 ring = torch.zeros((max(n, 1), B, 8), dtype=torch.float64, device=dev)
                 done = torch.zeros((B,), dtype=torch.int32, device=dev)
-                with _SsimRing(ops.plan, kind, n, B, dev) as sr:
+                with _SsimRing(ops.plan, kind, n, B, dev, record=save_loss) as sr:
                     L.check(L.lib().ddn_admm_run(ops.plan._h, _ptr(u), _ptr(w), _ptr(y), _ptr(z), _ptr(bd), float(t), float(rho), float(gamma), obj, n,
                                                  kind, float(tol), 2, _ptr(ring), _ptr(done), _ptr(sol)))
                     if kind:
                         vals = sr.values(ring, kind)
+                        if save_loss:
+                            extra = sr.metric_lists(ring, 0, 0, 1, int(done[0]))                     # (sol, b), admm:142-147
                 if kind:
                     dn = done.cpu().tolist()
                     losses = _loss_lists(vals, dn, 1, had_batch)                                     # i > 1 (admm:118)
@@ -276,7 +296,7 @@ def admm_solver(b: torch.Tensor, objective_function: str = "l1", t: float = 18, 
             params = {"t": t, "rho": rho, "gamma": gamma, "niters": niters, "objective_function": objective_function,
                       "loss_function": _loss_name(loss_function)}
             params.update(extra)
-            save_loss_data(losses, "admm", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
+            save_loss_data(losses[0] if (kind and had_batch) else losses, "admm", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
         out = _shape_out(sol, had_batch, lead).to(src)
         ret = [out]
         if kwargs.get("return_state"):
@@ -317,18 +337,23 @@ def primal_dr_splitting(problem: str, kernel: torch.Tensor, b: torch.Tensor, ima
         n = max(int(niters), 0)
         kind = _loss_kind(loss_function)
         obj = 0 if problem == "l1" else 1
+        # the reference starts both difference duals from b (pdr:88-89) and D1 == D2 keeps them equal: the library is
+        # told so and streams one array for the two (ddn.h, DDN_OBJ_DUALS_EQUAL)
+        twin = L.OBJ_DUALS_EQUAL if (init is None or bool(torch.equal(z2[1], z2[2]))) else 0
         losses, extra = [], {}
         with torch.cuda.device(dev):
             ops.plan.sync_stream()
-            if (kind or loss_function is None) and not save_loss:
+            if kind or (loss_function is None and not save_loss):
                 ring = torch.zeros((max(n, 1), B, 8), dtype=torch.float64, device=dev)
                 done = torch.zeros((B,), dtype=torch.int32, device=dev)
-                with _SsimRing(ops.plan, kind, n, B, dev) as sr:
-                    L.check(L.lib().ddn_pdr_run(ops.plan._h, _ptr(z1), _ptr(z2), _ptr(bd), float(t), float(rho), float(gamma), obj, n,
+                with _SsimRing(ops.plan, kind, n, B, dev, record=save_loss, b_every=1 if save_loss else None) as sr:
+                    L.check(L.lib().ddn_pdr_run(ops.plan._h, _ptr(z1), _ptr(z2), _ptr(bd), float(t), float(rho), float(gamma), obj | twin, n,
                                                 kind, float(tol), 3, _ptr(ring), _ptr(done)))
                     if kind:
                         vals = sr.values(ring, kind)
                         vb = sr.values(ring, kind, pair=1)
+                        if save_loss:
+                            extra = sr.metric_lists(ring, 1, 1, 2, int(done[0]))                     # (z1, b), pdr:146-154
                 if kind:
                     dn = done.cpu().tolist()
                     losses = _loss_lists(vals, dn, 2, had_batch)                                     # j > 1 (pdr:143)
@@ -364,7 +389,7 @@ def primal_dr_splitting(problem: str, kernel: torch.Tensor, b: torch.Tensor, ima
         if save_loss and losses:
             params = {"t": t, "gamma": gamma, "rho": rho, "niters": niters, "tol": tol}
             params.update(extra)
-            save_loss_data(losses, "primal_dr_splitting", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
+            save_loss_data(losses[0] if (kind and had_batch) else losses, "primal_dr_splitting", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
         solution = prox_box(z1, t)                                                                  # pdr:182-187
         out = _shape_out(solution, had_batch, lead).to(src)
         ret = [out]
@@ -412,14 +437,16 @@ def primal_dual_dr_splitting(b: torch.Tensor, kernel: torch.Tensor, niters: int 
         losses, extra = [], {}
         with torch.cuda.device(dev):
             ops.plan.sync_stream()
-            if (kind or loss_function is None) and not save_loss:
+            if kind or (loss_function is None and not save_loss):
                 ring = torch.zeros((max(n, 1), B, 8), dtype=torch.float64, device=dev)
                 done = torch.zeros((B,), dtype=torch.int32, device=dev)
-                with _SsimRing(ops.plan, kind, n, B, dev) as sr:
+                with _SsimRing(ops.plan, kind, n, B, dev, record=save_loss) as sr:
                     L.check(L.lib().ddn_pddr_run(ops.plan._h, _ptr(p), _ptr(q), _ptr(bd), float(t), float(rho), float(gamma), n,
                                                  kind, float(tol), 2, _ptr(ring), _ptr(done)))
                     if kind:
                         vals = sr.values(ring, kind)
+                        if save_loss:
+                            extra = sr.metric_lists(ring, 0, 0, 1, int(done[0]))                     # (clip(p), b), pddr:108-113
                 if kind:
                     dn = done.cpu().tolist()
                     losses = _loss_lists(vals, dn, 1, had_batch)                                     # k > 1 (pddr:103)
@@ -450,7 +477,7 @@ def primal_dual_dr_splitting(b: torch.Tensor, kernel: torch.Tensor, niters: int 
         if save_loss:
             params = {"t": t, "rho": rho, "gamma": gamma, "niters": niters, "tol": tol}
             params.update(extra)
-            save_loss_data(losses, "primal_dual_dr_splitting", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
+            save_loss_data(losses[0] if (kind and had_batch) else losses, "primal_dual_dr_splitting", _loss_name(loss_function), params, start_time, kwargs.get("results_dir"))
         x_sol = prox_box(p, 1)                                                                      # pddr:123
         out = _shape_out(x_sol, had_batch, lead).to(src)
         ret = [out]

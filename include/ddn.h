@@ -30,7 +30,7 @@ extern "C" {
 
 #define DDN_OK 0
 #define DDN_E_ARG (-1)       /* bad shape / dtype / enum / null pointer          */
-#define DDN_E_UNSUPPORTED (-2) /* size with a prime factor > 13, too large for LDS */
+#define DDN_E_UNSUPPORTED (-2) /* size with a prime factor > 2039, too large for LDS */
 #define DDN_E_HIP (-3)       /* a HIP runtime call failed                         */
 #define DDN_E_STATE (-4)     /* plan not set up for the requested operation       */
 
@@ -147,6 +147,14 @@ int ddn_reduce_static(int dtype, const void* x_dev, const void* y_dev, size_t n_
  * Synchronises the stream.  (A [B,C,H,W] input is B*C planes; the caller averages over C.) */
 int ddn_ssim(int dtype, const void* x_dev, const void* y_dev, int H, int W, int planes, double max_val, const float* g11_host, double* out_dev, void* stream);
 
+/* The same with the reference's `window_size` argument (core/loss.py:39): g_host holds the window_size normalised
+ * float32 factors of loss.py:75-81 evaluated for that size (window_size <= 63).  The SSIM map has
+ * H + 2 (window_size / 2) - window_size + 1 rows and likewise columns -- one more than the image for an even
+ * window, as the reference's conv2d calls with padding window_size // 2 produce -- and its mean is taken over
+ * that map.  Direct evaluation of the window_size^2 taps; synchronises the stream. */
+int ddn_ssim_window(int dtype, const void* x_dev, const void* y_dev, int H, int W, int planes, double max_val, const float* g_host, int window_size,
+                    double* out_dev, void* stream);
+
 /* X^T w of the blind-kernel step (op_math/python_code/apply_x_trans.py:4-46): w, x, out are
  * kernel_size x kernel_size arrays; out[i][j] = <w, x correlated with a one-hot kernel at (i, j) under
  * zero padding kernel_size / 2>.  kernel_size must be odd: for even sizes the reference's padded
@@ -158,11 +166,18 @@ int ddn_apply_x_trans(int dtype, const void* w_dev, const void* x_dev, int kerne
  * g11_host: the 11 window factors as for ddn_ssim; ssim_ring_dev: device doubles [n_iters][batch][2], caller-owned, which
  * the following *_run calls fill (the caller pre-fills it, e.g. with NaN): entry 0 of iteration i's slot = ssim of the
  * solver's primary pair after iteration i (cp: (x, b); admm: (sol, b); pdr: (z1, z1prev); pddr: (clip(p), b)),
- * entry 1 (pdr only, every 50th iteration from the first: the reference's logging cadence, pdr:137-141) = ssim(z1, b).
- * With tol_kind = DDN_LOSS_SSIM the stop test `loss < tol` is made on entry 0, on the device, as for the other kinds;
- * ddn_cp_run (which has no stop test) records whenever a ring is set.  ssim_ring_dev = NULL switches it off.
- * Cost per iteration: one pass over the two images (plus, for pdr, one copy of z1). */
+ * entry 1 (pdr only) = ssim(z1, b) at iterations 1, 1 + n, 1 + 2 n, ... with n = 50, the reference's logging
+ * cadence (pdr:137-141), unless ddn_plan_set_ssim_cadence says otherwise.
+ * Every *_run records whenever a ring is set, whatever tol_kind is -- except pdr's entry 0, whose pair (z1, z1prev)
+ * only exists as the stop criterion and is recorded with tol_kind = DDN_LOSS_SSIM only.  With tol_kind =
+ * DDN_LOSS_SSIM the stop test `loss < tol` is made on entry 0, on the device, as for the other kinds.
+ * ssim_ring_dev = NULL switches it off.
+ * Cost per iteration: one pass over the two images (plus, for pdr with tol_kind = DDN_LOSS_SSIM, one copy of z1). */
 int ddn_plan_set_ssim(ddn_plan* p, const float* g11_host, double max_val, double* ssim_ring_dev);
+
+/* primal DR: ssim(z1, b) (entry 1 of the ssim record) every `every` iterations from the first; 1 = at every
+ * iteration, which is what the reference records when it saves the loss history (pdr:146-154).  Default 50. */
+int ddn_plan_set_ssim_cadence(ddn_plan* p, int every);
 
 /* ---- solver loops -------------------------------------------------------------
  * Each *_run advances the iterate arrays in place by up to n_iters iterations of the
@@ -193,7 +208,12 @@ int ddn_admm_run(ddn_plan* p, void* u_dev, void* w_dev, void* y_dev, void* z_dev
                  double* loss_ring_dev, int* iters_done_dev, void* sol_out_dev);
 
 /* primal_dr_splitting loop body pdr:94-129.  z1: [batch][H][W]; z2: [3][batch][H][W].
- * Primary loss pair: (z1, z1prev) (pdr:144); secondary: (z1, b) (pdr:145-149). */
+ * Primary loss pair: (z1, z1prev) (pdr:144); secondary: (z1, b) (pdr:145-149).
+ * objective: 0 = l1, 1 = l2, optionally | DDN_OBJ_DUALS_EQUAL: the caller's statement that z2[1] and z2[2] hold the
+ * same bits on entry (the reference starts both from b, pdr:88-89, and D1 == D2, multiplying_matrix.py:55-59, keeps
+ * them equal): the run then streams one of the two arrays and copies it to the other at the end.  Nothing is checked:
+ * with the flag set and unequal arrays, z2[2] is overwritten by z2[1]'s trajectory. */
+#define DDN_OBJ_DUALS_EQUAL 0x100
 int ddn_pdr_run(ddn_plan* p, void* z1_dev, void* z2_dev, const void* b_dev,
                 double t, double rho, double gamma, int objective, int n_iters,
                 int tol_kind, double tol, int first_loss_iter,

@@ -102,6 +102,25 @@ def main():
     from deblur_denoise.primal_dr import algorithm as pdr_mod
     from deblur_denoise.primal_dual_dr import algorithm as pddr_mod
 
+    if args.only == "ssimwin":
+        # ---------------------------------------------------------------- ssim with other window sizes (core/loss.py:39)
+        sw = {}
+        torch.manual_seed(9)
+        a = torch.rand(48, 80)
+        bb = torch.rand(48, 80)
+        torch.manual_seed(10)
+        a4 = torch.rand(2, 1, 20, 33)    # (the reference window is (1, 1, ws, ws) with groups = C: one channel only)
+        b4 = (a4 + 0.1 * torch.randn(2, 1, 20, 33)).clamp(0, 1)
+        sw["a"], sw["b"], sw["a4"], sw["b4"] = to_np(a), to_np(bb), to_np(a4), to_np(b4)
+        for ws in (1, 3, 7, 8, 15, 16):
+            sw[f"w{ws}"] = np.asarray(to_np(refloss.ssim(a, bb, window_size=ws)), dtype=np.float64).reshape(-1)
+            sw[f"w{ws}_max255"] = np.asarray(to_np(refloss.ssim(a * 255, bb * 255, window_size=ws, max_val=255.0)), dtype=np.float64).reshape(-1)
+            sw[f"w{ws}_batch"] = np.asarray(to_np(refloss.ssim(a4, b4, window_size=ws)), dtype=np.float64).reshape(-1)
+        np.savez_compressed(os.path.join(out, "ssim_windows.npz"), **sw)
+        shutil.rmtree(scratch, ignore_errors=True)
+        print("wrote ssim_windows.npz to", out)
+        return
+
     if args.only == "xtrans":
         # ---------------------------------------------------------------- apply_x_trans
         from deblur_denoise.op_math.python_code.apply_x_trans import apply_x_trans

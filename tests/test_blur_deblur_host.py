@@ -78,3 +78,27 @@ def test_read_image_grey_scale_and_resize(tmp_path):
     assert torch.equal(rgb_to_grayscale(tg), tg)
     with pytest.raises(FileNotFoundError):
         read_image(str(tmp_path / "missing.png"))
+
+
+def test_read_image_tiff_is_scaled_twice_like_the_reference(tmp_path):
+    """utils/conv_utils.py:36-43: a '.tiff' file is read through PIL + ToTensor(), which scales 8-bit data to [0, 1], and
+    is then divided by 255 again like every other file -- callers of the reference receive values in [0, 1/255]."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    grey = rng.integers(0, 256, size=(12, 9), dtype=np.uint8)
+    p = str(tmp_path / "grey.tiff")
+    Image.fromarray(grey).save(p)
+    t = read_image(p, shape=None)
+    assert t.shape == (1, 12, 9) and t.dtype == torch.float32
+    assert torch.equal(t, (torch.from_numpy(grey).float().div(255) / 255).unsqueeze(0))
+    rgb = rng.integers(0, 256, size=(8, 10, 3), dtype=np.uint8)
+    p3 = str(tmp_path / "rgb.TIFF")
+    Image.fromarray(rgb).save(p3, format="TIFF")
+    f = torch.from_numpy(rgb).permute(2, 0, 1).float().div(255) / 255
+    exp = (0.2989 * f[0] + 0.587 * f[1] + 0.114 * f[2]).unsqueeze(0)
+    assert torch.allclose(read_image(p3, shape=None), exp, atol=1e-9)
+    # the same pixels under another extension take the single scaling
+    ppng = str(tmp_path / "grey.png")
+    Image.fromarray(grey).save(ppng)
+    assert torch.equal(read_image(ppng, shape=None), torch.from_numpy(grey).float().unsqueeze(0) / 255)
+

@@ -118,6 +118,17 @@ def test_losses(golden_dir):
     assert np.isinf(g["psnr_same"][0]) and np.isinf(float(O.psnr(a, a)))
 
 
+def test_ssim_window_sizes(golden_dir):
+    """core/loss.py:39: the window_size argument (even sizes give a map one row / column larger) and max_val."""
+    g = _load(golden_dir, "ssim_windows.npz")
+    a = torch.from_numpy(g["a"]); b = torch.from_numpy(g["b"])
+    a4 = torch.from_numpy(g["a4"]); b4 = torch.from_numpy(g["b4"])
+    for ws in (1, 3, 7, 8, 15, 16):
+        np.testing.assert_allclose(np.asarray(O.ssim(a, b, window_size=ws)).reshape(-1), g[f"w{ws}"], rtol=1e-6)
+        np.testing.assert_allclose(np.asarray(O.ssim(a * 255, b * 255, window_size=ws, max_val=255.0)).reshape(-1), g[f"w{ws}_max255"], rtol=1e-5)
+        np.testing.assert_allclose(np.asarray(O.ssim(a4, b4, window_size=ws)).reshape(-1), g[f"w{ws}_batch"], rtol=1e-6)
+
+
 def _t(a, dt):
     return torch.from_numpy(np.asarray(a)).to(dt)
 

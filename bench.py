@@ -188,6 +188,39 @@ def run_slab(args, dev, dt, rank, world, distributed, allreduce):
                         "frac": WORDS_ITER["admm_solver"] * esz * px / world * K / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "kernel": "whole iteration (per GPU): the split-row kernels, the two-pass column kernels and the exchanges"}}
     sv.close()
+    if world == 1 and not args.no_slab_check:
+        # the same problem on the single-plan path (ddn_admm_run on a whole-plane plan), same seed: the whole-image mse of
+        # the first timed iterations must agree.  Timed launch c is consuming launch W' + c of the run, which records
+        # the look-ahead solution of iteration W' + c - 1: row W' + c - 2 of ddn_admm_run's record.
+        del st, sol, b, sv
+        torch.cuda.empty_cache()
+        free2, _ = torch.cuda.mem_get_info(dev)
+        nchk, wm = min(3, K), max(Wm, 1)
+        if 26.0 * esz * px < free2:
+            import convex_optimization_amd as pkg
+            from convex_optimization_amd.plan import _ptr
+            gen.manual_seed(1000 + rank)
+            b1 = torch.rand((1, H, W), device=dev, dtype=dt, generator=gen)
+            s1 = tuple(torch.clamp(torch.randn(sh, device=dev, dtype=dt, generator=gen), 0, 1) for sh in ((1, H, W), (1, H, W), (3, 1, H, W), (3, 1, H, W)))
+            sol1 = torch.zeros_like(b1)
+            ops = pkg.DeblurDenoiseOperators(kern, b1[0], 1, 1, device=dev, batch=1, dtype=dt)
+            n1 = wm + nchk - 1
+            ring1 = torch.zeros((n1, 1, 8), dtype=torch.float64, device=dev)
+            done1 = torch.zeros((1,), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                ops.plan.sync_stream()
+                L.check(L.lib().ddn_admm_run(ops.plan._h, _ptr(s1[0]), _ptr(s1[1]), _ptr(s1[2]), _ptr(s1[3]), _ptr(b1), t, rho, gamma, obj, n1,
+                                             L.LOSS_PSNR, -1e300, 2, _ptr(ring1), _ptr(done1), _ptr(sol1)))
+                torch.cuda.synchronize(dev)
+            single = [float(v) for v in ring1[wm - 1:wm - 1 + nchk, 0, 2].cpu()]
+            slab = out["mse_per_iteration"][:nchk]
+            diff = max(abs(a - c) / max(abs(c), 1e-300) for a, c in zip(slab, single))
+            out["single_plan_check"] = {"what": "whole-image mse of (look-ahead solution, b) of the first timed iterations: slab entry points vs ddn_admm_run on one whole-plane plan, same seed",
+                                        "mse_slab": slab, "mse_single_plan": single, "max_rel_diff": diff, "agrees": bool(diff < 1e-4)}
+            ops.close()
+            assert diff < 1e-4, ("slab path and single-plan path disagree", slab, single)
+        else:
+            out["single_plan_check"] = {"skipped": f"needs about {26.0 * esz * px / 2**30:.0f} GiB of free device memory, {free2 / 2**30:.0f} GiB free"}
     return out
 
 
@@ -360,6 +393,7 @@ def main():
     ap.add_argument("--check-every", type=int, default=10)
     ap.add_argument("--planes", type=int, default=3072, help="batch1024rgb: planes in all (1024 RGB images)")
     ap.add_argument("--force-exchange", action="store_true")
+    ap.add_argument("--no-slab-check", action="store_true", help="slab32768 on one rank: skip the comparison with the single-plan path")
     ap.add_argument("--exchange-groups", type=int, default=0, help="slab32768: tile groups of the pipelined exchange (0 = automatic, 1 = one exchange)")
     args = ap.parse_args()
     if args.config == "batch1024rgb" and "--size" not in sys.argv:

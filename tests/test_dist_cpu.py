@@ -58,8 +58,10 @@ def _worker(rank, world, port, n_items, out):
         dist.destroy_process_group()
 
 
-def test_world2_gloo_loss_allreduce():
-    world, n_items = 2, 5
+@pytest.mark.parametrize("world,n_items", [(2, 5), (4, 11), (8, 8)])
+def test_world2_gloo_loss_allreduce(world, n_items):
+    """Loss records of rank-local images land at their global image index on every rank, and the global stop needs
+    every rank's images: two, four and eight ranks (uneven and one-image-per-rank shards)."""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n_items, out), nprocs=world, join=True)
@@ -126,6 +128,88 @@ def test_world2_gloo_slab_transposes(H, C, n_tiles):
         assert ok_cols and ok_back and ok_loss
         assert blocked == (H // world in (1, 2, 4, 8))   # (8, ...) runs the blocked layout, (6, ...) the repacking one
         assert spans[0][0] == 0 and spans[-1][1] == n_tiles
+
+
+def _slab_worker_groups(rank, world, port, H, C, n_tiles, groups, out):
+    """The exchanges of one image in row slabs with the tile counts of the large configurations, built and checked with
+    tensor expressions: the single all-to-all, and the tile groups of the pipelined column stage issued one by one in
+    the order SlabExchange.pipelined issues them."""
+    from convex_optimization_amd.slab import SlabExchange, SlabLayout
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lay = SlabLayout(H, 2 * C * (n_tiles - 1), C, n_tiles, rank, world)
+
+        def fill_rows(x):
+            tl = torch.arange(n_tiles).view(-1, 1, 1, 1)
+            sp = torch.arange(2).view(1, -1, 1, 1)
+            rw = (lay.row_lo + torch.arange(lay.rows)).view(1, 1, -1, 1)
+            cc = torch.arange(C).view(1, 1, 1, -1)
+            x.spec_rows.copy_(torch.complex((1000.0 * tl + 100.0 * sp + cc).float().expand(n_tiles, 2, lay.rows, C),
+                                            rw.float().expand(n_tiles, 2, lay.rows, C)))
+
+        def cols_ok(x):
+            # blocked layout: [source rank][local tile][spectrum][rows][C]
+            src = torch.arange(world).view(-1, 1, 1, 1, 1)
+            lt = (lay.tile_lo + torch.arange(lay.local_tiles)).view(1, -1, 1, 1, 1)
+            sp = torch.arange(2).view(1, 1, -1, 1, 1)
+            rr = torch.arange(lay.rows).view(1, 1, 1, -1, 1)
+            cc = torch.arange(C).view(1, 1, 1, 1, -1)
+            shape = (world, lay.local_tiles, 2, lay.rows, C)
+            want = torch.complex((1000.0 * lt + 100.0 * sp + cc).float().expand(shape), (src * lay.rows + rr).float().expand(shape))
+            return bool(torch.equal(x.spec_cols, want))
+
+        x = SlabExchange(lay, torch.complex64, "cpu")
+        assert x.blocked
+        fill_rows(x)
+        sent = x.spec_rows.clone()
+        x.rows_to_cols()
+        ok1 = cols_ok(x)
+        x.spec_rows.zero_()
+        x.cols_to_rows()
+        ok1 &= bool(torch.equal(x.spec_rows, sent))
+        # the pipelined exchange: groups of tiles, the same range rule on the sending and the receiving side
+        xg = SlabExchange(lay, torch.complex64, "cpu", exchange_groups=groups)
+        fill_rows(xg)
+        G = xg.groups
+        covered = torch.zeros(lay.local_tiles, dtype=torch.int32)
+        for g in range(G):
+            a, b = xg.group_range(lay.local_tiles, g)
+            covered[a:b] += 1
+        ok_cover = bool((covered == 1).all())
+        order = list(range(min(2, G)))                       # inbound runs two groups ahead (SlabExchange.pipelined)
+        for g in range(G):
+            if g + 2 < G:
+                order.append(g + 2)
+        for g in order:
+            xg._a2a_group(g, True)
+        ok2 = cols_ok(xg)
+        xg.spec_rows.zero_()
+        for g in range(G):
+            xg._a2a_group(g, False)
+        ok2 &= bool(torch.equal(xg.spec_rows, sent))
+        out[rank] = (ok1, ok2, ok_cover, G, lay.tile_spans)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,C,n_tiles,groups", [(4, 8, 2, 129, 4), (8, 8, 2, 129, 4), (8, 16, 1, 1025, 8), (4, 4, 1, 1025, 5), (2, 4, 2, 129, 4)])
+def test_gloo_slab_exchanges_with_the_tile_counts_of_the_large_images(world, H, C, n_tiles, groups):
+    """Four and eight ranks with the spectral tile counts of a 4096-pixel-wide image (129 tiles of 16 columns: an odd
+    count from column W/2, so the spans are uneven) and of a 32768-pixel-wide one (1025 tiles); the plain exchange and
+    the tile groups of the pipelined one, in both directions."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_slab_worker_groups, args=(world, _free_port(), H, C, n_tiles, groups, out), nprocs=world, join=True)
+    sizes = []
+    for r in range(world):
+        ok1, ok2, ok_cover, G, spans = out[r]
+        assert ok1 and ok2 and ok_cover, (r, ok1, ok2, ok_cover)
+        assert G == groups
+        sizes = [hi - lo for lo, hi in spans]
+        assert spans[0][0] == 0 and spans[-1][1] == n_tiles and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    assert max(sizes) - min(sizes) == 1          # the odd tile count: uneven spans
 
 
 def test_slab_layout_rejects_ragged_rows():

@@ -97,7 +97,7 @@ def test_forced_split_rows_fp64_vs_oracle(pkg, golden_dir, monkeypatch, H, W, R)
     assert not bad, res
 
 
-@pytest.mark.parametrize("H,W,dt,tol", [(8, 16384, torch.float32, 1e-5), (8, 8192, torch.float64, 1e-11)])
+@pytest.mark.parametrize("H,W,dt,tol", [(16, 16384, torch.float32, 1e-5), (16, 8192, torch.float64, 1e-11)])
 def test_chambolle_pock_with_injected_eigen_arrays_on_long_rows(pkg, golden_dir, H, W, dt, tol):
     """Rows beyond what one workgroup's LDS holds (16384 pixels in float32, 8192 in float64) with the reference's eigen
     arrays injected: Chambolle-Pock on the split row path with the row-spectral D."""

@@ -79,12 +79,13 @@ def _oracle(kern, b, stA, stP, stC, N):
 @pytest.mark.parametrize("H,W,kname,dt", [(64, 64, "gauss9", torch.float32), (48, 80, "motion15_45", torch.float32), (64, 64, "gauss9", torch.float64),
                                           (32, 1024, "motion15_45", torch.float32), (16, 4096, "motion15_45", torch.float32),
                                           (4096, 64, "motion15_45", torch.float32), (1024, 48, "gauss9", torch.float32),
-                                          (16, 8192, "motion15_45", torch.float32)])
+                                          (16, 8192, "motion15_45", torch.float32),
+                                          (16, 16384, "motion15_45", torch.float32), (16, 32768, "motion15_45", torch.float32)])
 def test_one_rank_slab_path_vs_oracle(H, W, kname, dt):
     """World size 1: the slab entry points (row stage on its own buffer layout, tile-range column stage)
     reproduce the oracle; covers the LDS row kernels, the register-resident row kernels (W = 1024, 4096),
-    the register-resident column kernels on a tile range (H = 4096, 1024), the whole-row kernel on the slab's
-    spectral layout (W = 8192) and fp64."""
+    the register-resident column kernels on a tile range (H = 4096, 1024), the whole-row kernels on the slab's
+    spectral layout (W = 8192, 16384 and 32768: the row width of the 32768 x 32768 configuration) and fp64."""
     import convex_optimization_amd.slab as S
     from convex_optimization_amd import _lib
     _lib.lib()
@@ -180,14 +181,16 @@ def test_one_rank_rccl_exchange_is_an_identity():
 
 @pytest.mark.parametrize("H,W,kname,dtname", [(64, 96, "gauss9", "float32"), (64, 64, "motion15_45", "float64"), (512, 1024, "motion15_45", "float32"),
                                               (4096, 96, "motion15_45", "float32"), (48, 80, "motion15_45", "float32"),
-                                              (4096, 32, "gauss9", "float64"), (32, 8192, "gauss9", "float32")])
+                                              (4096, 32, "gauss9", "float64"), (32, 8192, "gauss9", "float32"),
+                                              (32, 32768, "motion15_45", "float32"), (32, 16384, "gauss9", "float32")])
 def test_two_ranks_share_one_image(H, W, kname, dtname):
     """Two ranks, each owning half of the rows, against the single-GPU solve of the whole image (and the
     oracle at the small sizes): all-to-all both ways around every column stage, uneven tile spans,
     whole-image loss records from per-slab sums.  Rows per rank 32 (tile-generic column kernels reading
     the per-source row blocks), 256 and 2048 (the register-resident column kernels doing the same) and
     24 (not a power of two: the receiving side repacks); 4096 x 32 in fp64 runs the three-launch split column
-    transform on the row blocks."""
+    transform on the row blocks; 32 x 32768 and 32 x 16384 run the whole-row kernels of the 32768 x 32768
+    configuration on the slab's spectral layout, 1025 and 513 tiles over two ranks."""
     import torch.multiprocessing as mp
     world, N = 2, 20
     mgr = mp.Manager()

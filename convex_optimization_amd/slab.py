@@ -30,6 +30,8 @@ reference's early stop (admm:152-154, pdr:159-161, pddr:119-121) is reproduced: 
 four local sums are all-reduced (32 bytes, enqueued on the stream like the exchanges: no host round trip),
 every rank evaluates the same stop test on the device and a set flag freezes the iterates of all ranks at the
 reference's iteration; the host looks at the flag every `check_every` iterations to leave its launch loop.
+ssim and any callable that is not one of those four do not add up over slabs: for them the rows of all ranks are
+gathered every iteration and the function sees the whole image (WholeImageLoss), the reference's own host loop.
 """
 from __future__ import annotations
 
@@ -332,21 +334,83 @@ class SlabSolver:
         from .plan import _ptr
         self.L.check(self.L.lib().ddn_slab_loss(self.plan._h, self.lay.rows, _ptr(out)))
 
+    def gather_rows(self, rows: torch.Tensor) -> torch.Tensor:
+        """(H / P, W) rows of every rank -> the whole (H, W) image on every rank (an all-gather in rank order, which
+        is row order)."""
+        rows = rows.contiguous()
+        if self.world == 1:
+            return rows
+        staged = dist.get_backend(self.group) == "gloo" and rows.is_cuda
+        src = rows.cpu() if staged else rows
+        full = torch.empty((self.world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather(list(full.chunk(self.world)), src, group=self.group)
+        return full.to(rows.device) if staged else full
+
+    def agree(self, v: float) -> float:
+        """The value of the group's first rank on every rank: all ranks then take the same branch on it."""
+        if self.world == 1:
+            return v
+        cpu = dist.get_backend(self.group) == "gloo"
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if cpu else self.dev)
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        return float(t.item())
+
+
+class WholeImageLoss:
+    """loss_function(iterate, other) for the losses whose value is not a sum over row slabs: ssim (its windows reach
+    across slab borders) and any callable that is not one of this package's own.  The rows of every rank are gathered
+    and the function sees the whole image, as in the reference's loop (admm:139-154, pdr:143-161, pddr:103-121): one
+    all-gather and one host decision per iteration tested.  This package's ssim runs on the compute device; any other
+    callable gets its tensors on the device the caller's rows live on.  `values` keeps what was evaluated."""
+
+    def __init__(self, sv: SlabSolver, fn, tol: float, b_rows: torch.Tensor, caller_device):
+        from .core.loss import ssim
+        self.sv, self.fn, self.tol = sv, fn, float(tol)
+        self.where = None if fn is ssim else caller_device
+        self.b = self._place(sv.gather_rows(b_rows))
+        self.values = []
+        self.stopped = -1
+
+    def _place(self, t: torch.Tensor) -> torch.Tensor:
+        return t if self.where is None else t.to(self.where)
+
+    def test(self, it: int, a_rows: torch.Tensor, other_rows: Optional[torch.Tensor] = None) -> bool:
+        """Evaluate at iteration `it`; True when the solve stops here (loss < tol, the same answer on every rank)."""
+        a = self._place(self.sv.gather_rows(a_rows))
+        o = self.b if other_rows is None else self._place(self.sv.gather_rows(other_rows))
+        v = self.fn(a, o)
+        v = float(v.reshape(-1)[0]) if isinstance(v, torch.Tensor) else float(v)
+        v = self.sv.agree(v)
+        self.values.append(v)
+        if v < self.tol:
+            self.stopped = it
+            return True
+        return False
+
+
+WHOLE_IMAGE = -1      # the `kind` of a loss that needs the gathered image (WholeImageLoss)
+
 
 def _stop_args(kwargs):
-    """(kind, tol, check_every) of the optional early stop: loss_function must be one of this package's l1_loss, l2_loss,
-    mse, psnr (their sums add up over slabs); ssim and arbitrary callables need the whole image and are refused."""
+    """(kind, tol, check_every) of the optional early stop.  This package's l1_loss, l2_loss, mse and psnr add up over
+    slabs: kinds 1-4, tested on the device from all-reduced sums.  ssim and any other callable need the whole image:
+    kind WHOLE_IMAGE, evaluated every iteration on the gathered rows (check_every does not apply)."""
     fn = kwargs.get("loss_function")
     if fn is None:
         return 0, 0.0, 0
+    if not callable(fn):
+        raise ValueError("slab solvers: loss_function must be callable")
     kind = int(getattr(fn, "_ddn_kind", 0))
     if not 1 <= kind <= 4:
-        raise ValueError("slab solvers: loss_function must be l1_loss, l2_loss, mse or psnr of convex_optimization_amd.core")
+        kind = WHOLE_IMAGE
     return kind, float(kwargs.get("tol", 1e-6)), max(1, int(kwargs.get("check_every", 10)))
 
 
-def _finish_records(sv, ring, n, kind, H, W, group):
-    """(records of the iterations applied, iterations applied)."""
+def _finish_records(sv, ring, n, kind, H, W, group, whole=None):
+    """(records of the iterations applied, iterations applied).  With a whole-image loss the records are the values
+    the function returned, one per iteration tested."""
+    if whole is not None:
+        return torch.tensor(whole.values, dtype=torch.float64), (n if whole.stopped < 0 else whole.stopped)
     if kind:
         st = sv.stopped_at()
         nd = n if st < 0 else st
@@ -362,8 +426,10 @@ def admm_solver_slab(b_rows: torch.Tensor, image_shape: Tuple[int, int], objecti
                      gamma: float = 0.5, kernel=None, niters: int = 500, **kwargs):
     """admm_solver (admm/algorithm.py:20-201) for one image whose rows are spread over the ranks of
     `group`.  b_rows: this rank's (H / P, W) rows of the blurred image.  Returns this rank's rows of the
-    solution of the final solve (admm:160-173).  Runs up to niters - 1 iterations; with loss_function (l1_loss, l2_loss,
-    mse or psnr of this package), tol and check_every it stops where the reference does (admm:139-154).
+    solution of the final solve (admm:160-173).  Runs up to niters - 1 iterations; with loss_function, tol and
+    check_every it stops where the reference does (admm:139-154): l1_loss, l2_loss, mse or psnr of this package are tested
+    on the device from all-reduced sums, ssim or any other callable on the gathered image (return_losses then gives the
+    values of the function, one per iteration tested).
 
     Keyword extensions: init_state = (u, w, y, z) local slabs ((rows, W) and (3, rows, W)); without it
     the reference's draws (admm:49-54) are made for the WHOLE image on every rank from torch's CPU
@@ -397,6 +463,7 @@ def admm_solver_slab(b_rows: torch.Tensor, image_shape: Tuple[int, int], objecti
             sv.plan.sync_stream()
             st = (u, w, y, z)
             kind, tol, every = _stop_args(kwargs)
+            whole = WholeImageLoss(sv, kwargs["loss_function"], tol, bd, b_rows.device) if kind == WHOLE_IMAGE else None
             sv.rows(SOLVER_ADMM, st, bd, t, rho, gamma, obj, False, True)
             stopped = False
             for c in range(1, n + 1):
@@ -405,7 +472,11 @@ def admm_solver_slab(b_rows: torch.Tensor, image_shape: Tuple[int, int], objecti
                 # iteration is what `sol` holds when the flag freezes the rows (admm:118-154)
                 sv.rows(SOLVER_ADMM, st, bd, t, rho, gamma, obj, True, True, sol=sol if kind else None)
                 if c >= 2:
-                    if kind:
+                    if whole is not None:
+                        if c - 1 >= 2 and whole.test(c - 1, sol):   # loss(sol, b) for i > 1 (admm:118)
+                            stopped = True
+                            break
+                    elif kind:
                         sv.stop_test(kind, tol, c - 1, 2, ring[c - 2])
                         if c % every == 0 and sv.stopped_at() >= 0:
                             stopped = True
@@ -416,7 +487,10 @@ def admm_solver_slab(b_rows: torch.Tensor, image_shape: Tuple[int, int], objecti
                 sv.column_stage()
                 sv.rows(SOLVER_ADMM, st, bd, t, rho, gamma, obj, True, False, sol=sol, sol_only=True)
                 if n >= 1:
-                    if kind:
+                    if whole is not None:
+                        if n >= 2:
+                            whole.test(n, sol)
+                    elif kind:
                         sv.stop_test(kind, tol, n, 2, ring[n - 1])
                     else:
                         sv.loss_record(ring[n - 1])
@@ -425,18 +499,26 @@ def admm_solver_slab(b_rows: torch.Tensor, image_shape: Tuple[int, int], objecti
         if kwargs.get("return_state"):
             ret.append(tuple(v.to(b_rows.device) for v in st))
         if kwargs.get("return_losses"):
-            ret.append(_finish_records(sv, ring, n, kind, H, W, kwargs.get("group"))[0])
+            ret.append(_finish_records(sv, ring, n, kind, H, W, kwargs.get("group"), whole)[0])
         return ret[0] if len(ret) == 1 else tuple(ret)
     finally:
         sv.close()
 
 
-def _dr_slab(solver: int, n: int, sv: SlabSolver, st, bd, t, rho, gamma, obj, ring, kind=0, tol=0.0, every=0, first_it=1):
+def _dr_slab(solver: int, n: int, sv: SlabSolver, st, bd, t, rho, gamma, obj, ring, kind=0, tol=0.0, every=0, first_it=1, whole=None):
+    from .core.proximal_operators import prox_box
     sv.rows(solver, st, bd, t, rho, gamma, obj, False, True)
+    prev = torch.empty_like(st[0]) if (whole is not None and solver == SOLVER_PDR) else None
     for c in range(1, n + 1):
         sv.column_stage()
+        if prev is not None:
+            prev.copy_(st[0])
         sv.rows(solver, st, bd, t, rho, gamma, obj, True, c < n)
-        if kind:
+        if whole is not None:
+            # primal DR: loss(z1, z1prev) (pdr:143-161); primal-dual DR: loss(clip(p), b) (pddr:103-121)
+            if c >= first_it and (whole.test(c, st[0], prev) if solver == SOLVER_PDR else whole.test(c, prox_box(st[0], 1))):
+                break
+        elif kind:
             sv.stop_test(kind, tol, c, first_it, ring[c - 1])
             if c % every == 0 and sv.stopped_at() >= 0:
                 break
@@ -468,14 +550,15 @@ def primal_dr_splitting_slab(problem: str, kernel, b_rows: torch.Tensor, image_s
         with torch.cuda.device(dev):
             sv.plan.sync_stream()
             kind, tol, every = _stop_args(kwargs)
+            whole = WholeImageLoss(sv, kwargs["loss_function"], tol, bd, b_rows.device) if kind == WHOLE_IMAGE else None
             if n > 0:
-                _dr_slab(SOLVER_PDR, n, sv, (z1, z2), bd, t, rho, gamma, 0 if problem == "l1" else 1, ring, kind, tol, every, 3)   # j > 1 (pdr:143)
+                _dr_slab(SOLVER_PDR, n, sv, (z1, z2), bd, t, rho, gamma, 0 if problem == "l1" else 1, ring, kind, tol, every, 3, whole)   # j > 1 (pdr:143)
             torch.cuda.synchronize(dev)
         ret = [prox_box(z1, 1).to(b_rows.device)]                                                     # pdr:184
         if kwargs.get("return_state"):
             ret.append((z1.to(b_rows.device), z2.to(b_rows.device)))
         if kwargs.get("return_losses"):
-            ret.append(_finish_records(sv, ring, n, kind, H, W, kwargs.get("group"))[0])
+            ret.append(_finish_records(sv, ring, n, kind, H, W, kwargs.get("group"), whole)[0])
         return ret[0] if len(ret) == 1 else tuple(ret)
     finally:
         sv.close()
@@ -503,14 +586,15 @@ def primal_dual_dr_splitting_slab(b_rows: torch.Tensor, kernel, image_shape: Tup
         with torch.cuda.device(dev):
             sv.plan.sync_stream()
             kind, tol, every = _stop_args(kwargs)
+            whole = WholeImageLoss(sv, kwargs["loss_function"], tol, bd, b_rows.device) if kind == WHOLE_IMAGE else None
             if n > 0:
-                _dr_slab(SOLVER_PDDR, n, sv, (p, q), bd, t, rho, gamma, 0, ring, kind, tol, every, 2)   # k > 1 (pddr:103)
+                _dr_slab(SOLVER_PDDR, n, sv, (p, q), bd, t, rho, gamma, 0, ring, kind, tol, every, 2, whole)   # k > 1 (pddr:103)
             torch.cuda.synchronize(dev)
         ret = [prox_box(p, 1).to(b_rows.device)]                                                      # pddr:136
         if kwargs.get("return_state"):
             ret.append((p.to(b_rows.device), q.to(b_rows.device)))
         if kwargs.get("return_losses"):
-            ret.append(_finish_records(sv, ring, n, kind, H, W, kwargs.get("group"))[0])
+            ret.append(_finish_records(sv, ring, n, kind, H, W, kwargs.get("group"), whole)[0])
         return ret[0] if len(ret) == 1 else tuple(ret)
     finally:
         sv.close()

@@ -324,3 +324,83 @@ def test_two_ranks_early_stop_matches_oracle():
             assert res[name] < 1e-5, (r, name, res[name])
         assert res["pdr_loss"] < 2e-4
         assert res["pdr_iters"][0] < 40 and res["admm_iters"][0] < 39 and 2 < res["pddr_len"] < 38, res
+
+
+# ------------------------------------------------------------------ losses that need the whole image
+def _rmse(a, o):
+    return torch.sqrt(torch.mean((a - o) ** 2))
+
+
+def _whole_worker(rank, world, port, out):
+    import torch.distributed as dist
+    import convex_optimization_amd.slab as S
+    import convex_optimization_amd as pkg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        H = W = 64
+        kern, b, stA, stP, stC = _problem(H, W, "gauss9", torch.float32)
+        rows = H // world
+        sl = slice(rank * rows, (rank + 1) * rows)
+        res = {}
+        seen = []
+
+        def rmse_seen(a, o):
+            seen.append((tuple(a.shape), tuple(o.shape), a.device.type))
+            return _rmse(a, o)
+
+        # a callable of the caller's: stops where the oracle stops with the same function (admm:139-154)
+        ol = []
+        xo = O.admm_solver(b, "l1", t=18, rho=0.001, gamma=0.5, kernel=kern, niters=40, tol=2.2e-2 ** 0.5, loss_function=_rmse, init_state=stA, losses=ol)
+        x, rec = S.admm_solver_slab(b[sl], (H, W), "l1", kernel=kern, niters=40, tol=2.2e-2 ** 0.5, loss_function=rmse_seen,
+                                    init_state=[v[..., sl, :] for v in stA], return_losses=True)
+        res["admm_iters"] = (rec.shape[0], len(ol))
+        res["admm"] = rel(x.numpy(), xo[sl].numpy())
+        res["admm_loss"] = float(np.max(np.abs(rec.numpy() - np.asarray(ol))))
+        res["seen"] = seen[0]
+        # primal DR: loss(z1, z1prev) with the callable (pdr:143-161)
+        ol = []
+        xo = O.primal_dr_splitting("l1", kern, b, niters=60, loss_function=_rmse, tol=2e-4 ** 0.5, losses=ol)
+        x, rec = S.primal_dr_splitting_slab("l1", kern, b[sl], (H, W), niters=60, loss_function=_rmse, tol=2e-4 ** 0.5, return_losses=True)
+        res["pdr_iters"] = (rec.shape[0], len(ol))
+        res["pdr"] = rel(x.numpy(), xo[sl].numpy())
+        res["pdr_loss"] = float(np.max(np.abs(rec.numpy() - np.asarray(ol)) / np.asarray(ol)))
+        # ssim(clip(p), b) of the whole image every iteration, windows across the slab border included; no stop (tol below any value)
+        ol = []
+        xo = O.primal_dual_dr_splitting(b, kern, niters=25, init_state=stP, loss_function=O.ssim, tol=-2.0, losses=ol)
+        x, rec = S.primal_dual_dr_splitting_slab(b[sl], kern, (H, W), niters=25, loss_function=pkg.core.ssim, tol=-2.0,
+                                                 init_state=[v[..., sl, :] for v in stP], return_losses=True)
+        res["pddr_iters"] = (rec.shape[0], len(ol))
+        res["pddr"] = rel(x.numpy(), xo[sl].numpy())
+        res["pddr_loss"] = float(np.max(np.abs(rec.numpy() - np.asarray([float(v) for v in ol]))))
+        # ssim as the stop test: ssim(clip(p), b) rises from the random start, so a tolerance above its first values stops at once
+        ol = []
+        xo = O.primal_dual_dr_splitting(b, kern, niters=25, init_state=stP, loss_function=O.ssim, tol=0.9, losses=ol)
+        x, rec = S.primal_dual_dr_splitting_slab(b[sl], kern, (H, W), niters=25, loss_function=pkg.core.ssim, tol=0.9,
+                                                 init_state=[v[..., sl, :] for v in stP], return_losses=True)
+        res["pddr_stop_iters"] = (rec.shape[0], len(ol))
+        res["pddr_stop"] = rel(x.numpy(), xo[sl].numpy())
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_ssim_and_callable_losses_see_the_whole_image():
+    """ssim and a callable of the caller's as the slab solvers' loss_function: the rows of both ranks are gathered, the
+    function gets (H, W) tensors, both ranks stop at the oracle's iteration and the recorded values are the oracle's."""
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_whole_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        res = dict(out[r])
+        for name in ("admm", "pdr", "pddr", "pddr_stop"):
+            got, want = res[name + "_iters"]
+            assert got == want, (r, name, got, want)
+            assert res[name] < 1e-5, (r, name, res[name])
+        assert res["seen"] == ((64, 64), (64, 64), "cpu")          # the caller's rows were host tensors
+        assert res["admm_loss"] < 1e-5 and res["pdr_loss"] < 2e-3 and res["pddr_loss"] < 2e-5, res
+        assert 2 < res["admm_iters"][0] < 38 and 2 < res["pdr_iters"][0] < 58 and res["pddr_iters"][0] == 23 and res["pddr_stop_iters"][0] < 5, res

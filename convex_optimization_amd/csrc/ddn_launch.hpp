@@ -63,6 +63,15 @@ int row_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCom
     return launch_row_fn(st, k_solver_row<T, P, 4, 2, false, 1, WF, 512, 4>, grid, threads, lds, c, a);
 }
 
+// Double, W = 512 / 1024 / 2048 / 4096: the compile-time specialised transform as well (radix-8 passes, W / 8 threads,
+// one workgroup of up to eight wavefronts per CU at ~230 registers).  The run-time-radix transform in double does
+// not fit a lane's 256 registers -- its kernels keep 2.5 KB per lane in scratch memory -- and stays for the other widths.
+template <typename T, class P, int WF>
+int row_launch_d(hipStream_t st, int grid, int threads, size_t lds, bool spec, const RowCommon<T>& c, const typename P::Args& a) {
+    if (spec) return launch_row_fn(st, k_solver_row<T, P, 4, 2, true, 0, WF, 512, 2>, grid, threads, lds, c, a);
+    return launch_row_fn(st, k_solver_row<T, P, 4, 2, false, 0, WF, 512, 2>, grid, threads, lds, c, a);
+}
+
 // Wave-per-row kernels (W = 4096, float, 2-tap D; ddn_wrow.hpp), instantiated in ddn_wrow_*.hip.
 template <class P>
 int wrow_launch(hipStream_t st, int grid, const RowCommon<float>& c, const typename P::Args& a);
@@ -89,6 +98,15 @@ int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const R
         if (V == 0) return c.W == 4096 ? wrow_launch<P>(st, grid, c, a) : wrown_launch<P>(st, grid, c, a);
     }
     if (V == 4) {
+        if constexpr (sizeof(T) == 8) {
+            switch (c.W) {
+                case 512: return row_launch_d<T, P, 512>(st, grid, threads, lds, spec, c, a);
+                case 1024: return row_launch_d<T, P, 1024>(st, grid, threads, lds, spec, c, a);
+                case 2048: return row_launch_d<T, P, 2048>(st, grid, threads, lds, spec, c, a);
+                case 4096: return row_launch_d<T, P, 4096>(st, grid, threads, lds, spec, c, a);
+                default: break;
+            }
+        }
         if (spec) return launch_row_fn(st, k_solver_row<T, P, 4, 4, true, 0, 0, 256, 2>, grid, threads, lds, c, a);
         if constexpr (sizeof(T) == 4) {
             switch (c.W) {
@@ -110,6 +128,12 @@ int cp_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowComm
     return launch_row_fn(st, k_cp_row<T, 4, 2, false, WF, 512, 4>, grid, threads, lds, c, a);
 }
 
+template <typename T, int WF>
+int cp_launch_d(hipStream_t st, int grid, int threads, size_t lds, bool spec, const RowCommon<T>& c, const CpArgs<T>& a) {
+    if (spec) return launch_row_fn(st, k_cp_row<T, 4, 2, true, WF, 512, 2>, grid, threads, lds, c, a);
+    return launch_row_fn(st, k_cp_row<T, 4, 2, false, WF, 512, 2>, grid, threads, lds, c, a);
+}
+
 template <typename T>
 int cp_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const RowCommon<T>& c, const CpArgs<T>& a) {
     const bool spec = c.eDrow != nullptr;
@@ -117,6 +141,15 @@ int cp_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const Ro
         if (V == 0) return c.W == 4096 ? wrow_cp_launch(st, grid, c, a) : wrown_cp_launch(st, grid, c, a);
     }
     if (V == 4) {
+        if constexpr (sizeof(T) == 8) {
+            switch (c.W) {
+                case 512: return cp_launch_d<T, 512>(st, grid, threads, lds, spec, c, a);
+                case 1024: return cp_launch_d<T, 1024>(st, grid, threads, lds, spec, c, a);
+                case 2048: return cp_launch_d<T, 2048>(st, grid, threads, lds, spec, c, a);
+                case 4096: return cp_launch_d<T, 4096>(st, grid, threads, lds, spec, c, a);
+                default: break;
+            }
+        }
         if (spec) return launch_row_fn(st, k_cp_row<T, 4, 4, true, 0, 256, 2>, grid, threads, lds, c, a);
         if constexpr (sizeof(T) == 4) {
             switch (c.W) {

@@ -673,3 +673,25 @@ def test_apply_x_trans_vs_reference_golden(pkg, golden_dir):
         assert outd.is_cuda and rel(outd.cpu().numpy(), exp.numpy()) < 1e-14
     with pytest.raises(RuntimeError):
         pkg.op_math.apply_x_trans(torch.rand(4, 4), torch.rand(4, 4), 4)
+
+
+@pytest.mark.parametrize("H,W", [(16, 512), (20, 1024), (16, 2048), (16, 4096), (512, 512)])
+def test_float64_rows_of_512_to_4096_pixels_vs_oracle(pkg, golden_dir, H, W):
+    """float64 rows of 512 / 1024 / 2048 / 4096 pixels run the row kernels with the compile-time transform (W / 8 threads,
+    radix-8 passes): all four solvers, with the oracle's eigen arrays injected (row-spectral D, <= 1e-11) and with the
+    package's own float64 eigenvalues (two-tap D; the reference's arrays are complex64-derived, so that comparison is
+    held to the float32 bar, 1e-5).  512 x 512 is the float64 leg of the 512 x 512 configuration."""
+    from test_gpu_long_rows import _all_four, _problem
+    kern, b, stC, stA, stP = _problem(golden_dir, H, W, "gauss9", torch.float64)
+
+    def eig(t, s):
+        ops = O.DeblurDenoiseOperators(kern, b, t, s)
+        return {"K": ops.eig_arry_K, "D": ops.eig_arry_D1, "M": ops.eig_vals_mat}
+
+    N = 20 if H < 512 else 10
+    res = _all_four(pkg, kern, b, stC, stA, stP, N, eig=eig)
+    bad = {k: v for k, v in res.items() if not v < 1e-11}
+    assert not bad, ("injected", res)
+    res = _all_four(pkg, kern, b, stC, stA, stP, N)
+    bad = {k: v for k, v in res.items() if not v < 1e-5}
+    assert not bad, ("own eigenvalues", res)

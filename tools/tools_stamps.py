@@ -9,8 +9,9 @@ from convex_optimization_amd.core.blur import create_motion_blur_kernel
 H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda", 0)
 kern = create_motion_blur_kernel(15, 45)
-b = torch.rand(1, H, W, device=dev)
-ops = pkg.DeblurDenoiseOperators(kern, b[0], 2.0, device=dev, batch=1)
+dt = torch.float64 if os.environ.get("DDN_STAMPS_DTYPE") == "f64" else torch.float32
+b = torch.rand(1, H, W, device=dev, dtype=dt)
+ops = pkg.DeblurDenoiseOperators(kern, b[0], 2.0, device=dev, batch=1, dtype=dt)
 st = [b.clone(), torch.stack((b, b, b)).contiguous()]
 lib = L.lib()
 lib.ddn_plan_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]

@@ -239,24 +239,57 @@ struct Dft<T, 5, INV> {
     }
 };
 
-// Generic odd prime radix (7, 11, 13): direct O(R^2) evaluation with exact table twiddles.
+// Odd prime radix (7, 11, 13): direct evaluation with exact table twiddles w^k = c_k - i s_k, k = 1 .. (R - 1) / 2,
+// in the paired form
+//     out[q], out[R - q] = v0 + sum_a c_(a q) (v[a] + v[R - a])  -+  i sum_a s_(a q) (v[a] - v[R - a]),   a = 1 .. (R - 1) / 2
+// (the inverse flips the sign of the second sum): real coefficients, half the products of the plain double loop, and --
+// what matters more -- (R - 1) / 2 table reads and about 3 R live complex values.  The plain loop read a twiddle per
+// (a, q); the compiler hoisted all of them, and every kernel that contains the run-time-radix transform then kept
+// 1 - 3 KB per lane in scratch memory, whatever radices its launch actually ran.
 // tw is the length-n table exp(-2 pi i e / n) of the enclosing transform, n % R == 0.
 template <typename T, int R, bool INV>
 __device__ __forceinline__ void dft_prime(cx<T>* v, const Tw<T>& tw, int n) {
-    cx<T> o[R];
+    constexpr int HALF = (R - 1) / 2;
     const int step = n / R;
+    T c[HALF + 1], sn[HALF + 1];
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
-        cx<T> acc = v[0];
-#pragma unroll
-        for (int a = 1; a < R; ++a) {
-            cx<T> w = tw[((a * q) % R) * step];
-            acc = acc + (INV ? mulc(v[a], w) : v[a] * w);
-        }
-        o[q] = acc;
+    for (int k = 1; k <= HALF; ++k) {
+        const cx<T> w = tw[k * step];
+        c[k] = w.x;
+        sn[k] = -w.y;      // the table holds exp(-i ...): s_k = sin(2 pi k / R) > 0
     }
+    cx<T> sa[HALF + 1], da[HALF + 1];
+    cx<T> sum0 = v[0];
 #pragma unroll
-    for (int q = 0; q < R; ++q) v[q] = o[q];
+    for (int a = 1; a <= HALF; ++a) {
+        sa[a] = v[a] + v[R - a];
+        da[a] = v[a] - v[R - a];
+        sum0 = sum0 + sa[a];
+    }
+    const cx<T> v0 = v[0];
+    v[0] = sum0;
+#pragma unroll
+    for (int q = 1; q <= HALF; ++q) {
+        cx<T> A = v0, B = mk<T>((T)0, (T)0);
+#pragma unroll
+        for (int a = 1; a <= HALF; ++a) {
+            const int k = (a * q) % R;                       // compile-time after unrolling
+            const int kk = k <= HALF ? k : R - k;            // c_(R - k) = c_k, s_(R - k) = -s_k
+            A.x += c[kk] * sa[a].x;
+            A.y += c[kk] * sa[a].y;
+            if (k <= HALF) {
+                B.x += sn[kk] * da[a].x;
+                B.y += sn[kk] * da[a].y;
+            } else {
+                B.x -= sn[kk] * da[a].x;
+                B.y -= sn[kk] * da[a].y;
+            }
+        }
+        // forward: out[q] = A - i B, out[R - q] = A + i B; inverse: the other way round
+        const cx<T> iB = mk<T>(-B.y, B.x);
+        v[q] = INV ? A + iB : A - iB;
+        v[R - q] = INV ? A - iB : A + iB;
+    }
 }
 
 // One butterfly of pass s on column c: elements base + q*m, q = 0..R-1.

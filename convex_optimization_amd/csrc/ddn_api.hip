@@ -177,7 +177,6 @@ struct ddn_plan {
     size_t spec_plane = 0;     // complex elements of one image's half-spectrum (ntile * H * C)
     int col_threads = 0;
     int row_threads = 0;       // 0 = heuristic
-    int row_wg_per_cu = 2;
     int tune_cols = 0, tune_A = 0;
     int num_cu = 256;
     // device buffers (typed by dtype)
@@ -680,14 +679,12 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
         rc.V = -1; rc.threads = 256; rc.lds = 0; rc.grid = 1; rc.aligned = aligned;
         return true;
     }
-    bool eight_d = false;
     if (aligned && W % 4 == 0 && W <= 4096 && fft_min_threads(p->fw) <= 256) {   // (256: the launch bound of the V = 4 kernels)
         rc.V = 4;
         // float kernels specialised for these widths use eight pixels per thread (W/8 threads, radix-8
         // passes); every other V = 4 kernel sixteen pixels per thread (W/16 threads)
         // (double kernels of these widths too, with or without injected eigen arrays: row_launch_d)
         const bool eight = (sizeof(T) == 8 || !p->injected) && (W == 512 || W == 1024 || W == 2048 || W == 4096);
-        eight_d = eight && sizeof(T) == 8;
         rc.threads = eight ? W / 8 : std::min(256, std::max(64, (W / 16 + 63) / 64 * 64));
         if (!eight) rc.threads = std::max(rc.threads, fft_min_threads(p->fw));   // at most 256: within the kernels' launch bound
     } else {
@@ -699,8 +696,9 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
     if (rc.lds > kLdsMax) return false;
     int per_cu = (int)std::min<size_t>(8, kLdsMax / rc.lds);
     per_cu = std::max(1, std::min(per_cu, 2048 / rc.threads));
-    if (eight_d) per_cu = std::min(per_cu, std::max(1, 512 / rc.threads));   // compiled for two wavefronts per SIMD: eight per CU
-    else if (rc.V == 4) per_cu = std::min(per_cu, p->row_wg_per_cu);   // the V = 4 kernels are compiled for 2 workgroups of 256 per CU
+    // the V = 4 kernels are compiled for two wavefronts per SIMD, eight per CU: as many workgroups as that holds, so
+    // that a small image has all its rows in flight
+    if (rc.V == 4) per_cu = std::min(per_cu, std::max(1, 512 / rc.threads));
     rc.grid = std::max(1, std::min(work_items, p->num_cu * per_cu));
     return true;
 }

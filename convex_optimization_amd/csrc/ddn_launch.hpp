@@ -53,14 +53,17 @@ int launch_row_fn(hipStream_t st, K fn, int grid, int threads, size_t lds, const
     return DDN_OK;
 }
 
-// V = 4: 16-byte accesses, four pixel groups per thread, 256-thread workgroups, four per CU
-// (two with row-spectral D, which holds more state).  V = 1: any W up to 8192, scalar accesses.
 // V = 4: 16-byte accesses, four pixel groups per thread, 256-thread workgroups, two per CU.  Float
 // kernels for W = 512 / 1024 / 2048 / 4096 use the compile-time specialised transform and hold the
 // whole row's global loads in registers (PF).  V = 1: any W up to 8192, scalar accesses.
+// (two wavefronts per SIMD: with the whole row's loads held in registers these kernels need ~250 of them; compiled
+// for four per SIMD they kept 0.3-0.5 KB per lane in scratch memory and one 512 x 512 image ran 17 % slower)
+#ifndef DDN_ROWW_MINW
+#define DDN_ROWW_MINW 2
+#endif
 template <typename T, class P, int WF>
 int row_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCommon<T>& c, const typename P::Args& a) {
-    return launch_row_fn(st, k_solver_row<T, P, 4, 2, false, 1, WF, 512, 4>, grid, threads, lds, c, a);
+    return launch_row_fn(st, k_solver_row<T, P, 4, 2, false, 1, WF, 512, DDN_ROWW_MINW>, grid, threads, lds, c, a);
 }
 
 // Double, W = 512 / 1024 / 2048 / 4096: the compile-time specialised transform as well (radix-8 passes, W / 8 threads,
@@ -125,7 +128,7 @@ int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const R
 
 template <typename T, int WF>
 int cp_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCommon<T>& c, const CpArgs<T>& a) {
-    return launch_row_fn(st, k_cp_row<T, 4, 2, false, WF, 512, 4>, grid, threads, lds, c, a);
+    return launch_row_fn(st, k_cp_row<T, 4, 2, false, WF, 512, DDN_ROWW_MINW>, grid, threads, lds, c, a);
 }
 
 template <typename T, int WF>

@@ -1,9 +1,12 @@
 // Column stage for H = 64 R, R in {8, 16, 32} (512, 1024, 2048), float32, in ONE pass: one wavefront
 // per M = 64 / R ADJACENT spectral columns, all of them held in registers (wfft::fftN<R>).
 //
-// The M columns are 8 M contiguous bytes of every row of a tile (tiles are 8 or 16 columns wide), so a lane loads and
-// stores its rows directly (16-byte accesses, no staging through LDS): register q R + j of lane l
-// holds row 64 j + l of column q.  Resolvent mode: a workgroup is the wave pair (S0, S1) of one
+// The M columns are 8 M contiguous bytes of every row of a tile (tiles are 8 or 16 columns wide).  Register q R + j of
+// lane l holds row 64 j + l of column q, but global memory is accessed row-major: a wave instruction covers 64 / NV
+// rows x NV 16-byte pieces (NV = pieces of a row the wave owns) and the wave's transposition tile hands the pieces to
+// the row owners (rows_to_owner / owner_to_rows).  With one row per lane -- 64 rows x 16 bytes per instruction, NV
+// instructions per 16 NV-byte piece -- the same kernels moved 3.0 TB/s at most (a copy in that pattern: 3.0 TB/s;
+// 16 rows x 64 bytes: 4.9 TB/s; tools/ubench_pattern.hip).  Resolvent mode: a workgroup is the wave pair (S0, S1) of one
 // column group, which swaps register halves through the two transposition tiles for the pointwise
 // stage (as in ddn_wcol.hpp); multiplier mode: a workgroup is one wave.  With 33 KB of LDS per pair
 // four pairs share a CU and progress independently: one pair's loads overlap another's transforms.
@@ -21,6 +24,45 @@ using wrow::pin;
 using wrow::sched_fence;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+
+
+// Row-major global access <-> row-owner registers, within one wavefront, through its transposition tile.
+// rows_to_owner: on entry v[t] of lane (rs = lane / NV, q = lane % NV) holds piece q of row (64 / NV) t + rs of a slab of
+// 64 rows; on exit v[q] of lane l holds piece q of row l.  owner_to_rows: the way back.  Staged rows are NV + 1 pieces
+// apart (an odd pitch in 16-byte units: the owners' reads spread over all banks).
+template <int NV>
+__device__ __forceinline__ void rows_to_owner(f4 (&v)[NV], float* tile, int lane) {
+    if constexpr (NV > 1) {
+        constexpr int RPI = 64 / NV, PITCH = NV + 1;
+        f4* const t4 = reinterpret_cast<f4*>(tile);
+        const int rs = lane / NV, q = lane % NV;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) t4[(RPI * t + rs) * PITCH + q] = v[t];
+        wfft::wave_sync();
+#pragma unroll
+        for (int qq = 0; qq < NV; ++qq) v[qq] = t4[lane * PITCH + qq];
+        wfft::wave_sync();
+    }
+}
+template <int NV>
+__device__ __forceinline__ void owner_to_rows(f4 (&v)[NV], float* tile, int lane) {
+    if constexpr (NV > 1) {
+        constexpr int RPI = 64 / NV, PITCH = NV + 1;
+        f4* const t4 = reinterpret_cast<f4*>(tile);
+        const int rs = lane / NV, q = lane % NV;
+#pragma unroll
+        for (int qq = 0; qq < NV; ++qq) t4[lane * PITCH + qq] = v[qq];
+        wfft::wave_sync();
+#pragma unroll
+        for (int t = 0; t < NV; ++t) v[t] = t4[(RPI * t + rs) * PITCH + q];
+        wfft::wave_sync();
+    }
+}
+__device__ __forceinline__ f4 pack4(cx<float> a, cx<float> b) {
+    f4 v;
+    v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
+    return v;
+}
 
 // Frequency-side layout: lane q R + k1, register k2 holds frequency k1 + R k2 of column q; its
 // multiplier sits at (eKc + R k2)[eoff], eoff = column * pitch + k1 (per lane).
@@ -89,7 +131,6 @@ __global__ void __launch_bounds__((MODE == COL_RES2 ? 128 : 64) * NP, 2) k_wave_
     cx<float>* const Sarr = (MODE == COL_RES2 && h == 1) ? a.S1 : a.S0;
     const size_t gbase = opaque(((((size_t)plane * a.lay.ntile + tile) * a.lay.H) << cs) + (size_t)((sub * NP + pr) * M));
     float* const mytile = tiles + (size_t)wv * WFFT_TILE_FLOATS;
-    const unsigned loff = (unsigned)lane << cs;  // row `lane` of a 64-row slab, in elements
 
     // columns past the half-spectrum are tile padding: loaded, transformed and stored like the others
     // (their values are never read by a row kernel), with the multipliers of the last real column
@@ -101,19 +142,36 @@ __global__ void __launch_bounds__((MODE == COL_RES2 ? 128 : 64) * NP, 2) k_wave_
         constexpr int RH = R / 2;
         // own part into its final register, the partner's part into the register that will receive
         // the partner's contribution: wave 0 keeps S0, wave 1 keeps S1
+        // every global load of the wave is issued here, row-major (a wave instruction: 64 / M rows x 16 M bytes); piece t of
+        // slab jj waits in the registers of column t until its slab goes through the tile
+        constexpr int RPI = 64 / M;
+        const unsigned roff = ((unsigned)(lane / M) << cs) + (unsigned)(lane % M);
 #pragma unroll
         for (int jj = 0; jj < RH; ++jj) {
             const int j = h * RH + jj;                 // slab loaded by this wave (h is wave-uniform)
             const f4* const p = pairs + ((size_t)(64 * j) << cs);
 #pragma unroll
-            for (int q = 0; q < M; ++q) {
-                const f4 v = (p + q)[loff];
-                const cx<float> P = mk<float>(v.x, v.y), Q = mk<float>(v.z, v.w);
-                // registers are indexed statically: jj and jj + RH; which of the two is the own slot depends on h
-                d[q * R + jj] = P;                     // wave 0: own S0 at slab jj; wave 1: S0 of slab jj + RH, for the partner
-                d[q * R + jj + RH] = Q;                // wave 0: S1 of slab jj, for the partner; wave 1: own S1 at slab jj + RH
+            for (int t = 0; t < M; ++t) {
+                const f4 v = (p + ((size_t)(RPI * t) << cs))[roff];
+                d[t * R + jj] = mk<float>(v.x, v.y);
+                d[t * R + jj + RH] = mk<float>(v.z, v.w);
             }
         }
+        sched_fence();
+#pragma unroll
+        for (int jj = 0; jj < RH; ++jj) {
+            f4 v[M];
+#pragma unroll
+            for (int t = 0; t < M; ++t) v[t] = pack4(d[t * R + jj], d[t * R + jj + RH]);
+            rows_to_owner<M>(v, mytile, lane);
+#pragma unroll
+            for (int q = 0; q < M; ++q) {
+                // registers are indexed statically: jj and jj + RH; which of the two is the own slot depends on h
+                d[q * R + jj] = mk<float>(v[q].x, v[q].y);        // wave 0: own S0 at slab jj; wave 1: S0 of slab jj + RH, for the partner
+                d[q * R + jj + RH] = mk<float>(v[q].z, v[q].w);   // wave 0: S1 of slab jj, for the partner; wave 1: own S1 at slab jj + RH
+            }
+        }
+        // (a wave stages in its own tile and sends through its own tile: no barrier between the two)
         // send: wave 0 its S1 values (upper registers), wave 1 its S0 values (lower registers)
 #pragma unroll
         for (int q = 0; q < M; ++q) {
@@ -137,14 +195,31 @@ __global__ void __launch_bounds__((MODE == COL_RES2 ? 128 : 64) * NP, 2) k_wave_
         }
         __syncthreads();  // both tiles are transposition tiles again
     } else {
+        constexpr int NV = M / 2, RPI = 64 / NV;        // 16-byte pieces (two columns) of a row
+        const unsigned roff = ((unsigned)(lane / NV) << (cs - 1)) + (unsigned)(lane % NV);
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const f4* const p = reinterpret_cast<const f4*>(Sarr + gbase + ((size_t)(64 * j) << cs) + (RB ? (size_t)(j >> a.rb_sh6) * (size_t)a.rb_extra : (size_t)0));
 #pragma unroll
-            for (int q2 = 0; q2 < M / 2; ++q2) {
-                const f4 v = (p + q2)[loff >> 1];
-                d[(2 * q2) * R + j] = mk<float>(v.x, v.y);
-                d[(2 * q2 + 1) * R + j] = mk<float>(v.z, v.w);
+            for (int t = 0; t < NV; ++t) {
+                const f4 v = (p + ((size_t)(RPI * t) << (cs - 1)))[roff];
+                d[(2 * t) * R + j] = mk<float>(v.x, v.y);
+                d[(2 * t + 1) * R + j] = mk<float>(v.z, v.w);
+            }
+        }
+        if constexpr (NV > 1) {
+            sched_fence();
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                f4 v[NV];
+#pragma unroll
+                for (int t = 0; t < NV; ++t) v[t] = pack4(d[(2 * t) * R + j], d[(2 * t + 1) * R + j]);
+                rows_to_owner<NV>(v, mytile, lane);
+#pragma unroll
+                for (int q2 = 0; q2 < NV; ++q2) {
+                    d[(2 * q2) * R + j] = mk<float>(v[q2].x, v[q2].y);
+                    d[(2 * q2 + 1) * R + j] = mk<float>(v[q2].z, v[q2].w);
+                }
             }
         }
     }
@@ -195,34 +270,51 @@ __global__ void __launch_bounds__((MODE == COL_RES2 ? 128 : 64) * NP, 2) k_wave_
             }
         }
         __syncthreads();
+        // the received halves go into the registers that held what was sent: every slab's pairs are then complete in
+        // (d[q R + jj], d[q R + jj + RH]) and the partner's tile is free again
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+#pragma unroll
+            for (int jj = 0; jj < RH; ++jj) {
+                const cx<float> x = theirs[(q * RH + jj) * 64 + lane];
+                const cx<float> lo = d[q * R + jj], hi = d[q * R + jj + RH];
+                // wave 0: (own S0 of slab jj, received S1 of slab jj); wave 1: (received S0 of slab jj + RH, own S1)
+                d[q * R + jj] = h == 0 ? lo : x;
+                d[q * R + jj + RH] = h == 0 ? x : hi;
+            }
+        }
+        __syncthreads();  // both waves have read their partner's tile: the tiles are staging space from here on
         f4* const pairs = reinterpret_cast<f4*>(a.S0) + opaque(gbase);
+        constexpr int RPI = 64 / M;
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
+        const unsigned roff = ((unsigned)(lane_s / M) << cs) + (unsigned)(lane_s % M);
 #pragma unroll
         for (int jj = 0; jj < RH; ++jj) {
             const int j = h * RH + jj;
             f4* const p = pairs + ((size_t)(64 * j) << cs);
+            f4 v[M];
 #pragma unroll
-            for (int q = 0; q < M; ++q) {
-                const cx<float> x = theirs[(q * RH + jj) * 64 + lane];
-                const cx<float> lo = d[q * R + jj], hi = d[q * R + jj + RH];
-                // wave 0: (own S0 of slab jj, received S1 of slab jj); wave 1: (received S0 of slab jj + RH, own S1)
-                const cx<float> P = h == 0 ? lo : x, Q = h == 0 ? x : hi;
-                f4 v;
-                v.x = P.x; v.y = P.y; v.z = Q.x; v.w = Q.y;
-                (p + q)[loff] = v;
-            }
+            for (int q = 0; q < M; ++q) v[q] = pack4(d[q * R + jj], d[q * R + jj + RH]);
+            owner_to_rows<M>(v, mytile, lane_s);
+#pragma unroll
+            for (int t = 0; t < M; ++t) (p + ((size_t)(RPI * t) << cs))[roff] = v[t];
         }
     } else {
         cx<float>* const Sout = Sarr + opaque(gbase);
+        constexpr int NV = M / 2, RPI = 64 / NV;
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
+        const unsigned roff = ((unsigned)(lane_s / NV) << (cs - 1)) + (unsigned)(lane_s % NV);
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             f4* const p = reinterpret_cast<f4*>(Sout + ((size_t)(64 * j) << cs) + (RB ? (size_t)(j >> a.rb_sh6) * (size_t)a.rb_extra : (size_t)0));
+            f4 v[NV];
 #pragma unroll
-            for (int q2 = 0; q2 < M / 2; ++q2) {
-                f4 v;
-                v.x = d[(2 * q2) * R + j].x; v.y = d[(2 * q2) * R + j].y;
-                v.z = d[(2 * q2 + 1) * R + j].x; v.w = d[(2 * q2 + 1) * R + j].y;
-                (p + q2)[loff >> 1] = v;
-            }
+            for (int q2 = 0; q2 < NV; ++q2) v[q2] = pack4(d[(2 * q2) * R + j], d[(2 * q2 + 1) * R + j]);
+            owner_to_rows<NV>(v, mytile, lane_s);
+#pragma unroll
+            for (int t = 0; t < NV; ++t) (p + ((size_t)(RPI * t) << (cs - 1)))[roff] = v[t];
         }
     }
 }

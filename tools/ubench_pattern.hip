@@ -6,6 +6,9 @@
 //   pattern 1  per-lane rows (k_wave_colN): a wave instruction covers 64 rows x 16 bytes, four instructions per 64-byte piece
 //   pattern 2  contiguous: the workgroup's 256 KB as one block (what 4-column tiles would give), 1 KB per wave instruction
 //   pattern 3  half tile per workgroup pair emulation: 8 rows x 128 bytes per wave instruction (whole lines)
+// and for one spectrum alone (8-byte elements, 128 bytes a row; the multiplier mode of Chambolle-Pock):
+//   pattern 4  quarter tile, four waves, two workgroups per CU: a wave instruction covers 16 rows x 32 bytes
+//   pattern 5  half tile, eight waves: a wave instruction covers 8 rows x 64 bytes
 // build: hipcc --offload-arch=gfx950 -O3 -o build/ubench_pattern tools/ubench_pattern.hip ; run: build/ubench_pattern
 #include <hip/hip_runtime.h>
 
@@ -75,6 +78,64 @@ __global__ void __launch_bounds__(512, 2) k_pat(f4* __restrict__ buf, int nplane
     if (nplanes < 0) lds[tid] = 0.f;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int PAT, bool WRITE>
+__global__ void __launch_bounds__(PAT == 4 ? 256 : 512, 2) k_pat8(f2* __restrict__ buf, int nplanes) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int PER_TILE = PAT == 4 ? 4 : 2;
+    const int per_plane = kTiles * PER_TILE;
+    const int plane = blockIdx.x / per_plane, b = blockIdx.x % per_plane;
+    int tile, sub;
+    if (PAT == 4) {
+        const int quarter = 4 * (8 * (b >> 5) + (b & 7)) + ((b >> 3) & 3);
+        tile = quarter >> 2; sub = quarter & 3;
+    } else {
+        const int oct = 2 * (8 * (b >> 4) + (b & 7)) + ((b >> 3) & 1);
+        tile = oct >> 1; sub = oct & 1;
+    }
+    f2* const tbase = buf + ((size_t)plane * kTiles + tile) * kRows * kPitch;
+    f2 v[64];
+    unsigned off;
+    if (PAT == 4) off = (unsigned)((16 * wv + (lane >> 2)) * kPitch + sub * 4 + (lane & 3));
+    else off = (unsigned)((8 * wv + (lane >> 3)) * kPitch + sub * 8 + (lane & 7));
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = (tbase + (size_t)(64 * i) * kPitch)[off];
+    if (WRITE) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            v[i].x += 1.f;
+            (tbase + (size_t)(64 * i) * kPitch)[off] = v[i];
+        }
+    } else {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) s += v[i].x + v[i].y;
+        if (s == 12345.678f) lds[tid] = s;
+    }
+    if (nplanes < 0) lds[tid] = 0.f;
+}
+
+template <int PAT, bool WRITE>
+double run8(f2* buf, int nplanes, int reps) {
+    const int grid = nplanes * kTiles * (PAT == 4 ? 4 : 2);
+    const size_t lds = PAT == 4 ? 66 * 1024 : 133 * 1024;
+    const int nt = PAT == 4 ? 256 : 512;
+    CHECK(hipFuncSetAttribute((const void*)k_pat8<PAT, WRITE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_pat8<PAT, WRITE>), dim3(grid), dim3(nt), lds, 0, buf, nplanes);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_pat8<PAT, WRITE>), dim3(grid), dim3(nt), lds, 0, buf, nplanes);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
 template <int PAT, bool WRITE>
 double run(f4* buf, int nplanes, int reps) {
     const int grid = nplanes * kTiles * 4;
@@ -113,6 +174,17 @@ int main() {
         ROW(1)
         ROW(2)
         ROW(3)
+        {
+            f2* b8 = reinterpret_cast<f2*>(buf);
+            const double bytes8 = bytes / 2;     // the same tiles with 8-byte elements: half of the buffer
+#define ROW8(P)                                                                                                     \
+    t = run8<P, false>(b8, nplanes, reps);                                                                          \
+    printf("  pattern %d read        %8.1f us  %7.1f GB/s\n", P, t * 1e3, bytes8 / t / 1e6);                       \
+    t = run8<P, true>(b8, nplanes, reps);                                                                           \
+    printf("  pattern %d read+write  %8.1f us  %7.1f GB/s (both directions)\n", P, t * 1e3, 2 * bytes8 / t / 1e6);
+            ROW8(4)
+            ROW8(5)
+        }
         CHECK(hipFree(buf));
     }
     return 0;

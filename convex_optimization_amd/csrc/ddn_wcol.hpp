@@ -211,7 +211,7 @@ __device__ __forceinline__ void res2_pair(cx<float> (&d)[64], const cx<float>* e
         const int r = 2 * rr + HH;
         const cx<float> X = theirs[rr * 64 + lane];
         const cx<float> P = HH == 0 ? d[r] : X, Q = HH == 0 ? X : d[r];
-        const float g = gscale / (1.f + cK * (e[rr].x * e[rr].x + e[rr].y * e[rr].y) + cDd);
+        const float g = gscale * __builtin_amdgcn_rcpf(1.f + cK * (e[rr].x * e[rr].x + e[rr].y * e[rr].y) + cDd);   // hardware reciprocal (1 ulp): a correctly rounded divide is ten instructions
         const cx<float> U = (P + mulc(Q, e[rr])) * g;
         const cx<float> V = e[rr] * U;
         d[r] = HH == 0 ? U : V;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void dense_column(const Args& a, int plane, float* ti
         const int i0 = SW(tid + k * NT);
         if (MODE == COL_RES2) {
             const cx<float> P = L[i0], Q = L[4096 + i0];
-            const float g = a.gscale / (1.f + a.cK * (e.x * e.x + e.y * e.y) + cDd);
+            const float g = a.gscale * __builtin_amdgcn_rcpf(1.f + a.cK * (e.x * e.x + e.y * e.y) + cDd);
             const cx<float> U = (P + mulc(Q, e)) * g;
             L[i0] = U;
             L[4096 + i0] = e * U;

@@ -81,7 +81,7 @@ __device__ __forceinline__ void res2_pairN(cx<float> (&d)[64], const cx<float>* 
         const int r = RB + rr;
         const cx<float> X = theirs[rr * 64 + lane];
         const cx<float> P = HH == 0 ? d[r] : X, Q = HH == 0 ? X : d[r];
-        const float g = gscale / (1.f + cK * (e[rr].x * e[rr].x + e[rr].y * e[rr].y) + cDd);
+        const float g = gscale * __builtin_amdgcn_rcpf(1.f + cK * (e[rr].x * e[rr].x + e[rr].y * e[rr].y) + cDd);   // hardware reciprocal (1 ulp): a correctly rounded divide is ten instructions
         const cx<float> U = (P + mulc(Q, e[rr])) * g;
         const cx<float> V = e[rr] * U;
         d[r] = HH == 0 ? U : V;

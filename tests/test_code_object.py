@@ -107,3 +107,35 @@ def test_whole_row_kernels_fit_their_occupancy(kernels):
         assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 256, (n, k[".vgpr_count"])
         limit = 0 if "k_row_whole_cp" in n else 768
         assert k[".private_segment_fixed_size"] <= limit, (n, k[".private_segment_fixed_size"], k.get(".vgpr_spill_count"))
+
+
+def test_lds_row_kernels_scratch_budget(kernels):
+    """The workgroup-per-row LDS kernels (csrc/ddn_kernels.hpp).  Those with the compile-time transform (the eighth
+    template argument of k_solver_row, the fifth of k_cp_row: the row length) fit their registers: no scratch in float,
+    at most 256 B per lane in double (row-spectral D at 1024 pixels parks a few registers).  Those with the run-time-radix
+    transform contain a butterfly for every radix; written carelessly, the prime-radix ones (one table read per term)
+    made every such kernel keep 1 - 3 KB per lane in scratch whatever radices it ran.  Budgets: 16-byte-access kernels
+    128 B in float (512 B for Chambolle-Pock's, which holds two rows, and with row-spectral D) and 768 B in double,
+    scalar-access kernels (compiled for 1024 threads: 128 registers) 1280 B."""
+    import re
+    fam = {n: k for n, k in kernels.items() if "k_solver_row" in n or "k_cp_row" in n}
+    assert len(fam) >= 60, len(fam)
+    seen = {"fixed": 0, "generic": 0}
+    for n, k in fam.items():
+        scratch = k[".private_segment_fixed_size"]
+        double = n.startswith("_Z12k_solver_rowId") or n.startswith("_Z8k_cp_rowId")
+        # mangled template arguments: ...ILi<V>ELi<NG>ELb<SPEC>E[Li<PF>E]Li<WF>ELi<MAXT>ELi<MINW>E
+        ints = [int(v) for v in re.findall(r"Li(\d+)E", n)]
+        wf, maxt = ints[-3], ints[-2]
+        if wf != 0:
+            seen["fixed"] += 1
+            assert scratch <= (256 if double else 0), (n, scratch)
+            assert k[".vgpr_count"] <= 256, (n, k[".vgpr_count"])
+        else:
+            seen["generic"] += 1
+            limit = 1280 if maxt == 1024 else (768 if double else 128)
+            spec = "Lb1E" in n
+            if (spec or "k_cp_row" in n) and maxt != 1024 and not double:
+                limit = 512      # a second transform pair per row (row-spectral D) / two rows per workgroup
+            assert scratch <= limit, (n, scratch, limit)
+    assert seen["fixed"] >= 40 and seen["generic"] >= 16, seen

@@ -15,7 +15,7 @@ f64 = len(sys.argv) > 3 and sys.argv[3] == "f64"
 dt = torch.float64 if f64 else torch.float32
 TOL = 1e-11 if f64 else 1e-5
 rng = np.random.default_rng(seed)
-small = [16, 24, 32, 34, 48, 51, 64, 80, 96, 100, 128, 200, 256, 300, 500, 512, 1000, 1024]
+small = [16, 24, 32, 34, 48, 51, 56, 64, 77, 80, 91, 96, 100, 104, 128, 143, 200, 256, 300, 500, 512, 1000, 1024]   # (56 ... 143: radices 7, 11, 13)
 large = [2048, 4096] if f64 else [2048, 4096, 8192, 16384, 32768]
 fails = []
 for case in range(ncases):

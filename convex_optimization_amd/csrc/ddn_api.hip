@@ -40,7 +40,7 @@ namespace {
 
 
 // ------------------------------------------------------------------------------ factorisation
-constexpr int kMaxPrimeRadix = 2039;   // largest prime below 2 x 1024 threads (see fft_min_threads)
+constexpr int kMaxPrimeRadix = 8191;   // largest prime below 8 x 1024 threads (see fft_min_threads)
 
 bool factorize(int n, FftDesc& d) {
     std::memset(&d, 0, sizeof(d));
@@ -131,12 +131,15 @@ bool factorize(int n, FftDesc& d) {
     return true;
 }
 
-// The runtime-radix pass of ddn_fft.hpp (prime factors above 13) evaluates at most two outputs per thread and round,
-// and a round is at least one whole butterfly: a workgroup that runs a pass of radix r needs 2 * threads >= r.
+// The runtime-radix pass of ddn_fft.hpp (prime factors above 13) evaluates at most two outputs per thread and round
+// (eight for radices above 2048), and a round is at least one whole butterfly: a workgroup that runs a pass of radix r
+// needs 2 * threads >= r (8 * threads >= r).
 int fft_min_threads(const FftDesc& d) {
     int m = 64;
-    for (int s = 0; s < d.npass; ++s)
-        if (d.radix[s] > 16) m = std::max(m, ((d.radix[s] + 1) / 2 + 63) / 64 * 64);
+    for (int s = 0; s < d.npass; ++s) {
+        const int r = d.radix[s];
+        if (r > 16) m = std::max(m, ((r + (r > 2048 ? 7 : 1)) / (r > 2048 ? 8 : 2) + 63) / 64 * 64);
+    }
     return m;
 }
 
@@ -301,7 +304,7 @@ bool choose_col(ddn_plan* p) {
             for (int a = 2; (long)a * a <= (long)H; ++a) {
                 if (H % a == 0) A = a;
             }
-            if (A == 1) return false;
+            if (A == 1 && cs < 0) return false;   // (a prime height that fits with narrower tiles keeps them: slow, but it runs)
         }
     }
     p->A = A;
@@ -1653,7 +1656,7 @@ static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, 
     if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) p->num_cu = prop.multiProcessorCount;
     if (!factorize(W, p->fw) || !factorize(H, p->fh)) {
         delete p;
-        return fail(DDN_E_UNSUPPORTED, "plan_create: image size has a prime factor > 2039");
+        return fail(DDN_E_UNSUPPORTED, "plan_create: image size has a prime factor > 8191");
     }
     const bool ok = dtype == DDN_F32 ? choose_col<float>(p) : choose_col<double>(p);
     if (!ok) {
@@ -1675,7 +1678,7 @@ static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, 
         }
         if (!p->long_R) {
             delete p;
-            return fail(DDN_E_UNSUPPORTED, "plan_create: row length too large (W must be 2, 4, 8 or 16 times a length of at most 4096 with prime factors <= 509)");
+            return fail(DDN_E_UNSUPPORTED, "plan_create: row length too large (W must be 2, 4, 8 or 16 times a length of at most 4096 with prime factors <= 509: the split-row kernels run 256 threads)");
         }
     }
     int rc = dtype == DDN_F32 ? plan_alloc<float>(p) : plan_alloc<double>(p);

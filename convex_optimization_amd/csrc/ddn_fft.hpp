@@ -8,6 +8,7 @@
 // so a forward / pointwise multiply / inverse round trip needs no reordering pass: multiplier
 // arrays are stored once in the same digit-reversed order.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #define DDN_MAXPASS 8
@@ -329,10 +330,12 @@ __device__ __forceinline__ void butterfly(cx<T>* lds, const Tw<T>& tw, int n, in
 // rounds over whole butterflies: compute up to KREG outputs per thread into registers, barrier, store, barrier.
 // Every thread of the workgroup must call it (it contains barriers).  A round is at least one whole butterfly, so
 // the launch must provide KREG * nt >= r threads-times-registers (the host's fft_min_threads() sizes workgroups for
-// it): with fewer, outputs tid + i * nt >= KREG * nt of a butterfly would never be computed.
-template <typename T, bool INV>
-__device__ __forceinline__ void prime_pass(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
-    constexpr int KREG = 2;
+// it): with fewer, outputs tid + i * nt >= KREG * nt of a butterfly would never be computed.  KREG = 2 serves radices up
+// to 2 x 1024 threads; beyond that (up to 8 x 1024) eight outputs per thread, and float sums are accumulated in double
+// (thousands of terms: a float accumulator alone would use up the 1e-5 the iterates are held to).
+template <typename T, bool INV, int KREG>
+__device__ __forceinline__ void prime_pass_k(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
+    using A = typename std::conditional<KREG == 2, T, double>::type;
     const int r = d.radix[s], m = d.m[s], twmul = d.twmul[s], step = d.n / r;
     const int per = (d.n / r) << cshift;
     const int total = per * narr;
@@ -352,16 +355,19 @@ __device__ __forceinline__ void prime_pass(cx<T>* lds, int narr, int arr_stride,
                 const int blk = bf / m, jj = bf - blk * m;
                 const int base = blk * (m * r) + jj, e = jj * twmul;
                 const cx<T>* L = lds + a * arr_stride;
-                cx<T> sum = mk<T>((T)0, (T)0);
+                A sx = (A)0, sy = (A)0;
                 int aq = 0;                              // (a2 * q) mod r
                 for (int a2 = 0; a2 < r; ++a2) {
                     cx<T> v = L[SW(((base + a2 * m) << cshift) + c)];
                     if (INV && m > 1 && a2 > 0) v = mulc(v, tw[a2 * e]);
                     const cx<T> wq = tw[aq * step];
-                    sum = sum + (INV ? mulc(v, wq) : v * wq);
+                    const cx<T> t = INV ? mulc(v, wq) : v * wq;
+                    sx += (A)t.x;
+                    sy += (A)t.y;
                     aq += q;
                     if (aq >= r) aq -= r;
                 }
+                cx<T> sum = mk<T>((T)sx, (T)sy);
                 if (!INV && m > 1 && q > 0) sum = sum * tw[q * e];
                 acc[i] = sum;
                 where[i] = a * arr_stride + SW(((base + q * m) << cshift) + c);
@@ -373,6 +379,11 @@ __device__ __forceinline__ void prime_pass(cx<T>* lds, int narr, int arr_stride,
             if (where[i] >= 0) lds[where[i]] = acc[i];
         __syncthreads();
     }
+}
+template <typename T, bool INV>
+__device__ __forceinline__ void prime_pass(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int s, int cshift, int tid, int nt) {
+    if (d.radix[s] > 2 * nt) prime_pass_k<T, INV, 8>(lds, narr, arr_stride, tw, d, s, cshift, tid, nt);   // uniform over the workgroup
+    else prime_pass_k<T, INV, 2>(lds, narr, arr_stride, tw, d, s, cshift, tid, nt);
 }
 
 // One full pass over `narr` arrays of n * C elements each (array a starts at lds + a*arr_stride).

@@ -30,7 +30,7 @@ extern "C" {
 
 #define DDN_OK 0
 #define DDN_E_ARG (-1)       /* bad shape / dtype / enum / null pointer          */
-#define DDN_E_UNSUPPORTED (-2) /* size with a prime factor > 2039, too large for LDS */
+#define DDN_E_UNSUPPORTED (-2) /* size with a prime factor > 8191, too large for LDS */
 #define DDN_E_HIP (-3)       /* a HIP runtime call failed                         */
 #define DDN_E_STATE (-4)     /* plan not set up for the requested operation       */
 

@@ -1,6 +1,6 @@
 """Image sizes with prime factors above 13 (the reference's torch.fft takes any length: 2-D transforms of 34 x 38 or
 97 x 101 images just work there).  Those factors run in a runtime-radix pass (csrc/ddn_fft.hpp, prime_pass); all four
-solvers against the CPU oracle, fp32 and fp64, and the documented limit: a prime factor above 2039 is refused."""
+solvers against the CPU oracle, fp32 and fp64, and the documented limit: a prime factor above 8191 is refused."""
 import numpy as np
 import pytest
 import torch
@@ -37,7 +37,7 @@ def test_sizes_with_large_prime_factors_fp64(pkg, golden_dir):
 # The runtime-radix pass gives every thread at most two outputs of a round, and a round is at least one butterfly: a
 # radix above 2 x 64 needs more than the smallest workgroup.  Widths and heights whose launch shapes used to come
 # with 64 threads: W = 2 * 251 and W = 509 (scalar-access rows), W = 4 * 257 (16-byte-access rows), H = 263 (column
-# tiles narrowed to one column), and radices beyond 509 up to the limit (1021 rows, 2 * 523 columns).
+# tiles narrowed to one column), and radices beyond 509 (1021 rows, 2 * 523 columns).
 @pytest.mark.parametrize("H,W", [(16, 2 * 251), (16, 509), (16, 4 * 257), (263, 16), (16, 1021), (2 * 523, 16)])
 def test_radices_above_two_wavefronts_fp32(pkg, golden_dir, H, W):
     kern, b, stC, stA, stP = _problem(golden_dir, H, W, "gauss5", torch.float32)
@@ -75,9 +75,33 @@ def test_radices_above_two_wavefronts_fp64(pkg, golden_dir, H, W):
     assert not bad, res
 
 
+# Radices above 2 x 1024: eight outputs per thread and round, float sums accumulated in double.  16 x 4099 and 16 x 2053
+# are rows of prime length (scalar-access row kernels with 576 / 1024 threads), 2063 x 16 a prime height that only fits
+# the LDS with one-column tiles, 8191 the largest radix there is.
+@pytest.mark.parametrize("H,W", [(16, 4099), (16, 2053), (2063, 16), (16, 8191)])
+def test_radices_above_two_thousand_fp32(pkg, golden_dir, H, W):
+    kern, b, stC, stA, stP = _problem(golden_dir, H, W, "gauss5", torch.float32)
+    res = _all_four(pkg, kern, b, stC, stA, stP, 4)
+    bad = {k: v for k, v in res.items() if not v < 1e-5}
+    assert not bad, res
+
+
+def test_radix_above_two_thousand_fp64(pkg, golden_dir):
+    H, W = 16, 2053
+    kern, b, stC, stA, stP = _problem(golden_dir, H, W, "gauss5", torch.float64)
+
+    def eig(t, s):
+        o2 = O.DeblurDenoiseOperators(kern, b, t, s)
+        return {"K": o2.eig_arry_K, "D": o2.eig_arry_D1, "M": o2.eig_vals_mat}
+
+    res = _all_four(pkg, kern, b, stC, stA, stP, 4, eig=eig)
+    bad = {k: v for k, v in res.items() if not v < 1e-11}
+    assert not bad, res
+
+
 def test_prime_factor_above_the_limit_is_refused(pkg):
-    """2053 is the first prime above the limit: plan creation fails with a message, nothing silently falls back."""
+    """8209 is the first prime above the limit: plan creation fails with a message, nothing silently falls back."""
     from convex_optimization_amd._lib import DdnError
-    b = torch.rand(2053, 16)
+    b = torch.rand(8209, 16)
     with pytest.raises(DdnError, match="prime factor"):
         pkg.primal_dr_splitting("l1", torch.ones(3, 3) / 9, b, niters=2)

@@ -650,7 +650,7 @@ struct RowCfg {
 // Row workgroup shape: V = 4 pixels per lane-access (16 B) and four groups per thread when the
 // arrays are 16-byte aligned and W <= 4096; otherwise scalar accesses, eight pixels per thread.
 template <typename T>
-bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool cp = false) {
+bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool cp = false, bool admm = false) {
     const int W = p->W;
     if (p->long_R) {
         // rows wider than 8192 pixels: the three-kernel split transform (ddn_long.hpp); V = -1 marks it
@@ -658,11 +658,17 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
         return true;
     }
     // A wavefront of the register-resident kernels works through its rows alone (two transforms and the pixel
-    // loop in sequence, 35-40 us whatever the image size); with fewer wavefronts than a quarter of the CUs
-    // (half for Chambolle-Pock, whose wavefronts carry twice the rows) the workgroup-per-row LDS kernels
-    // finish sooner (measured at 512 x 512 and 1024 x 1024, one to four images).  DDN_FORCE_WAVE_ROWS=1 overrides.
+    // loop in sequence, 35-40 us whatever the image size); with few wavefronts the workgroup-per-row LDS kernels
+    // finish sooner.  W = 4096: fewer than a quarter of the CUs (half for Chambolle-Pock, whose wavefronts carry twice
+    // the rows).  W = 512 / 1024 / 2048, where the LDS kernels with the compile-time transform and 16-byte accesses
+    // compete (measured, one to sixteen images, row launch in us, LDS / wavefront kernels -- primal DR: 512^2 x 8 41 / 44,
+    // 1024^2 x 2 49 / 42, x 4 84 / 49; ADMM, whose nine arrays leave the wavefront kernel two loads in flight: 512^2 x 8
+    // 46 / 80, x 16 81 / 97, 1024^2 x 4 90 / 91; Chambolle-Pock: 1024^2 x 2 28 / 38, x 4 44 / 42): fewer than two
+    // wavefronts per CU, four for ADMM.  DDN_FORCE_WAVE_ROWS=1 / DDN_NO_WAVE_ROWS=1 override.
     const int wave_items = (W == 4096) ? work_items : p->batch * p->H / ((cp ? 2 : 1) * std::max(1, 4096 / W));
-    const bool wave_pays = wave_items > (cp ? p->num_cu / 2 : p->num_cu / 4) || p->env.force_wave_rows;
+    int wave_thresh = cp ? p->num_cu / 2 : p->num_cu / 4;
+    if (W != 4096 && aligned && W % 4 == 0) wave_thresh = admm ? 4 * p->num_cu : 2 * p->num_cu - 1;
+    const bool wave_pays = wave_items > wave_thresh || p->env.force_wave_rows;
     if (sizeof(T) == 4 && p->wtwW && !p->injected && p->H % ((cp ? 2 : 1) * (4096 / W)) == 0 && wave_pays && !p->env.no_wave_rows) {
         // one wavefront per 4096 / W consecutive rows, twice as many for Chambolle-Pock (ddn_wrown.hpp)
         rc.V = 0; rc.threads = 64; rc.lds = 0;
@@ -1258,7 +1264,7 @@ int admm_run_impl(ddn_plan* p, void* u, void* w, void* y, void* z, const void* b
     const size_t plane = (size_t)p->batch * p->H * p->W;
     RowCfg cfg;
     const bool al = aligned16(u) && aligned16(w) && aligned16(y) && aligned16(z) && aligned16(b) && aligned16(sol) && ((plane * sizeof(T)) % 16 == 0);
-    if (!row_cfg<T>(p, al, p->batch * p->H, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    if (!row_cfg<T>(p, al, p->batch * p->H, cfg, false, true)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
     NyqDense nyq_guard(p, cfg.V == 0, true);
     typename AdmmP<T>::Args a;
     RowCommon<T> rc0;
@@ -1421,7 +1427,7 @@ int slab_rows_impl(ddn_plan* p, int solver, int rows, void* spec, void* s0, void
     RowCfg cfg;
     const bool al = aligned16(s0) && aligned16(s1) && (!s2 || aligned16(s2)) && (!s3 || aligned16(s3)) && aligned16(b) && (!sol || aligned16(sol)) &&
                     ((plane * sizeof(T)) % 16 == 0);
-    if (!row_cfg<T>(p, al, rows, cfg)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
+    if (!row_cfg<T>(p, al, rows, cfg, false, solver == 0)) return fail(DDN_E_UNSUPPORTED, "row length not supported");
     RowCommon<T> c = row_common<T>(p, cfg.V, consume != 0, produce != 0);   // c.stop: the plan's flag, see ddn_slab_begin / ddn_slab_stop_test
     const size_t C = (size_t)1 << p->cs;
     c.S0 = (cx<T>*)spec;

@@ -298,7 +298,14 @@ bool choose_col(ddn_plan* p) {
         if (H % A) return false;
     } else {
         int cs = fit(H, 2);
-        if (cs < 0 || (1 << cs) < minc) {
+        // Between the heights whose columns fit the LDS eight (four in double) at a time and those that must be split
+        // there is a range -- 1243 ... 2490 rows -- where four (two) columns fit: ONE pass over 32-byte pieces then beats
+        // three passes of the split transform whenever the transform has at most four radix passes (measured, one
+        // image, Mpx-it/s, split / one pass: 1280^2 6.7 k / 12.7 k, 1536^2 7.2 / 14.0, 1920^2 8.6 / 18.4 -- 15.7 with the
+        // split's tiles 16 wide -- against 2160^2 11.7 / 11.3 and 2400^2 11.9 / 11.9 with five passes; double 1920^2
+        // 10.2 / 11.5).
+        const bool narrow_one_pass = cs >= 0 && (1 << cs) >= minc / 2 && p->fh.npass <= 4;
+        if (!narrow_one_pass && (cs < 0 || (1 << cs) < minc)) {
             // split H = A x B, A the largest factor <= sqrt(H)
             A = 1;
             for (int a = 2; (long)a * a <= (long)H; ++a) {
@@ -327,7 +334,8 @@ bool choose_col(ddn_plan* p) {
         auto wave_len = [](int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096; };
         const bool wave = sizeof(T) == 4 && (wave_len(H) || wave_len(p->W));
         const size_t spectra = 2 * (size_t)H * p->Wh * sizeof(cx<T>);
-        if (!wave && spectra <= ((size_t)32 << 20)) {
+        // (nor for a split transform, whose launches have a workgroup per tile AND segment, nor below the 64-byte piece)
+        if (!wave && A == 1 && (1 << c2) >= minc && spectra <= ((size_t)32 << 20)) {
             const int cus = p->num_cu > 0 ? p->num_cu : 256;
             while (lim > 0 && ((p->Wh + (1 << lim) - 1) >> lim) < cus) --lim;
         }
@@ -513,9 +521,21 @@ int launch_col_one(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t 
     return launch_col_fn<T, MODE, 0>(p, a, nblocks, threads, lds);
 }
 
-inline int col_threads_for(const ddn_plan* p, const FftDesc& fd, int cs, int narr) {
+// Threads of a tile-generic column workgroup: sixteen elements per thread, or -- while the launch's workgroups leave
+// wavefronts free on the chip (a small image: one workgroup per narrow tile) -- four or eight per thread: a 500-row column pair on
+// one wavefront is a chain of twenty dependent butterflies per pass (one image, column launch in us, 64 / 256 threads:
+// 300^2 25 / 17, 500^2 36 / 18; 1000^2, 256 / 512 threads: 42 / 26).
+inline int col_threads_for(const ddn_plan* p, const FftDesc& fd, int cs, int narr, int nblocks = 1 << 30) {
     const int n = fd.n;
-    int threads = std::min(1024, std::max(64, (((n << cs) * narr) / 16 + 63) / 64 * 64));
+    const int elems = (n << cs) * narr;
+    int threads = std::min(1024, std::max(64, (elems / 16 + 63) / 64 * 64));
+    for (int per_thread : {4, 8}) {
+        const int wide = std::min(1024, std::max(64, (elems / per_thread + 63) / 64 * 64));
+        if (wide > threads && (long)nblocks * (wide / 64) <= (long)p->num_cu * 8) {
+            threads = wide;
+            break;
+        }
+    }
     if (p->col_threads > 0) threads = std::max(64, std::min(1024, p->col_threads / 64 * 64));
     return std::max(threads, fft_min_threads(fd));
 }
@@ -604,7 +624,7 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
         a.nseg = 1; a.row_stride = 1; a.seg_stride = 0;
         a.outer = 0;
         a.lf = lf;
-        return launch_col_one<T, MODE>(p, a, nplanes * a.lay.ntile, col_threads_for(p, a.fd, cs, NARR), col_lds_bytes<T>(a.fd.n, cs, NARR));
+        return launch_col_one<T, MODE>(p, a, nplanes * a.lay.ntile, col_threads_for(p, a.fd, cs, NARR, nplanes * a.lay.ntile), col_lds_bytes<T>(a.fd.n, cs, NARR));
     }
     // split transform: strided length-A stage, middle length-B stage (with the pointwise algebra),
     // strided length-A inverse stage
@@ -695,6 +715,18 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
         // (double kernels of these widths too, with or without injected eigen arrays: row_launch_d)
         const bool eight = (sizeof(T) == 8 || !p->injected) && (W == 512 || W == 1024 || W == 2048 || W == 4096);
         rc.threads = eight ? W / 8 : std::min(256, std::max(64, (W / 16 + 63) / 64 * 64));
+        if (!eight && sizeof(T) == 4 && !p->injected) {
+            // a row gets more threads (8 or 4 pixels each instead of 16) while the image's rows leave wavefronts for it
+            // (eight per CU): a 1000-pixel row on one wavefront takes 74 us, and 1000 rows are half of what the chip holds
+            // (one 1000^2 image: 7.1 -> 8.8 k Mpx-it/s with two wavefronts per row; 1920 rows already fill it: 18.3 -> 16.5 k)
+            for (int per_thread : {4, 8}) {
+                const int thr = std::max(64, ((W + per_thread - 1) / per_thread + 63) / 64 * 64);
+                if (thr <= 512 && work_items <= p->num_cu * (8 / (thr / 64))) {     // (whole workgroups per CU: 8 / wavefronts each)
+                    rc.threads = std::max(rc.threads, thr);
+                    break;
+                }
+            }
+        }
         if (!eight) rc.threads = std::max(rc.threads, fft_min_threads(p->fw));   // at most 256: within the kernels' launch bound
     } else {
         if (W > 8192) return false;

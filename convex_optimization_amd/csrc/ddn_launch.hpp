@@ -120,6 +120,12 @@ int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const R
                 default: break;
             }
         }
+        // float, any width: one, two or four pixel groups per thread -- the launch shape (row_cfg) gives a row as many
+        // threads as the image's rows leave wavefronts for; the kernel with the fewest groups that covers the row is taken
+        if constexpr (sizeof(T) == 4) {
+            if (threads <= 512 && threads * 4 >= c.W) return launch_row_fn(st, k_solver_row<T, P, 4, 1, false, 0, 0, 512, 2>, grid, threads, lds, c, a);
+            if (threads <= 512 && threads * 8 >= c.W) return launch_row_fn(st, k_solver_row<T, P, 4, 2, false, 0, 0, 512, 2>, grid, threads, lds, c, a);
+        }
         return launch_row_fn(st, k_solver_row<T, P, 4, 4, false, 0, 0, 256, 2>, grid, threads, lds, c, a);
     }
     if (spec) return launch_row_fn(st, k_solver_row<T, P, 1, 8, true, 0, 0, 1024, 1>, grid, threads, lds, c, a);
@@ -162,6 +168,10 @@ int cp_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const Ro
                 case 4096: return cp_launch_w<T, 4096>(st, grid, threads, lds, c, a);
                 default: break;
             }
+        }
+        if constexpr (sizeof(T) == 4) {
+            if (threads <= 512 && threads * 4 >= c.W) return launch_row_fn(st, k_cp_row<T, 4, 1, false, 0, 512, 2>, grid, threads, lds, c, a);
+            if (threads <= 512 && threads * 8 >= c.W) return launch_row_fn(st, k_cp_row<T, 4, 2, false, 0, 512, 2>, grid, threads, lds, c, a);
         }
         return launch_row_fn(st, k_cp_row<T, 4, 4, false, 0, 256, 2>, grid, threads, lds, c, a);
     }

@@ -116,6 +116,9 @@ bool factorize(int n, FftDesc& d) {
             while ((1 << ms) < d.m[s]) ++ms;
         }
         d.mshift[s] = ms;
+        auto magic = [](int dv) { return dv <= 1 ? 0u : (unsigned)((((unsigned long long)1 << 32) + (unsigned)dv - 1) / (unsigned)dv); };
+        d.rmagic[s] = magic(r);
+        d.mmagic[s] = magic(d.m[s]);
         if ((r & (r - 1)) == 0) {
             int rs = 0;
             while ((1 << rs) < r) ++rs;

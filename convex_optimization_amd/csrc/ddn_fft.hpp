@@ -56,7 +56,13 @@ struct FftDesc {
     int m[DDN_MAXPASS];
     int mshift[DDN_MAXPASS];  // log2(m) when m is a power of two, else -1
     int twmul[DDN_MAXPASS];
+    // ceil(2^32 / radix) and ceil(2^32 / m) (0 when the divisor is 1): the quotient of n by d is the high word of
+    // n * ceil(2^32 / d), exactly, whenever n * d < 2^32 -- every index here is below 2^17 and every divisor below 2^13.
+    // A run-time integer division costs some forty instructions, and the position of a frequency needs two per pass.
+    unsigned rmagic[DDN_MAXPASS];
+    unsigned mmagic[DDN_MAXPASS];
 };
+__device__ __forceinline__ int fast_div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
 
 // Twiddle source exp(-2 pi i e / n), e in [0, n).  Short transforms keep the whole table in LDS; long
 // ones keep two small tables and form w^e = w^(64*(e>>6)) * w^(e&63) with one complex multiply, so
@@ -111,9 +117,9 @@ __device__ __forceinline__ int pos_of_freq(const FftDesc& d, int k) {
     }
     for (int s = 0; s < d.npass; ++s) {
         const int r = d.radix[s];
-        const int q = k % r;
-        k /= r;
-        pos += q * d.m[s];
+        const int kq = fast_div(k, d.rmagic[s]);
+        pos += (k - kq * r) * d.m[s];
+        k = kq;
     }
     return pos;
 }
@@ -129,7 +135,8 @@ __device__ __forceinline__ int freq_of_pos(const FftDesc& d, int p) {
     }
     for (int s = 0; s < d.npass; ++s) {
         const int r = d.radix[s];
-        const int q = (p / d.m[s]) % r;
+        const int pm = fast_div(p, d.mmagic[s]);
+        const int q = pm - fast_div(pm, d.rmagic[s]) * r;
         k += q * mult;
         mult *= r;
     }
@@ -398,7 +405,10 @@ __device__ __forceinline__ void fft_pass(cx<T>* lds, int narr, int arr_stride, c
     const int total = per * narr;
     for (int w = tid; w < total; w += nt) {
         int a = 0, ww = w;
-        if (narr > 1) {
+        if (narr == 2) {                 // (the two half-spectra of the column kernels: no division)
+            a = w >= per ? 1 : 0;
+            ww = w - (a ? per : 0);
+        } else if (narr > 2) {
             a = w / per;
             ww = w - a * per;
         }
@@ -409,7 +419,7 @@ __device__ __forceinline__ void fft_pass(cx<T>* lds, int narr, int arr_stride, c
             blk = bf >> ms;
             jj = bf & (m - 1);
         } else {
-            blk = bf / m;
+            blk = fast_div(bf, d.mmagic[s]);
             jj = bf - blk * m;
         }
         const int base = blk * (m * r) + jj;
@@ -509,7 +519,10 @@ __device__ __forceinline__ void fixed_pass(cx<T>* lds, int narr, int arr_stride,
     const int total = per * narr;
     for (int w = tid; w < total; w += nt) {
         int a = 0, ww = w;
-        if (narr > 1) {
+        if (narr == 2) {                 // (the two half-spectra of the column kernels: no division)
+            a = w >= per ? 1 : 0;
+            ww = w - (a ? per : 0);
+        } else if (narr > 2) {
             a = w / per;
             ww = w - a * per;
         }

@@ -115,7 +115,7 @@ def test_lds_row_kernels_scratch_budget(kernels):
     at most 256 B per lane in double (row-spectral D at 1024 pixels parks a few registers).  Those with the run-time-radix
     transform contain a butterfly for every radix; written carelessly, the prime-radix ones (one table read per term)
     made every such kernel keep 1 - 3 KB per lane in scratch whatever radices it ran.  Budgets: 16-byte-access kernels
-    128 B in float (512 B for Chambolle-Pock's, which holds two rows, and with row-spectral D) and 768 B in double,
+    128 B in float (512 B for Chambolle-Pock's, which holds two rows, and with row-spectral D) and 1024 B in double,
     scalar-access kernels (compiled for 1024 threads: 128 registers) 1280 B."""
     import re
     fam = {n: k for n, k in kernels.items() if "k_solver_row" in n or "k_cp_row" in n}
@@ -133,7 +133,7 @@ def test_lds_row_kernels_scratch_budget(kernels):
             assert k[".vgpr_count"] <= 256, (n, k[".vgpr_count"])
         else:
             seen["generic"] += 1
-            limit = 1280 if maxt == 1024 else (768 if double else 128)
+            limit = 1280 if maxt == 1024 else (1024 if double else 128)
             spec = "Lb1E" in n
             if (spec or "k_cp_row" in n) and maxt != 1024 and not double:
                 limit = 512      # a second transform pair per row (row-spectral D) / two rows per workgroup

@@ -716,8 +716,9 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
         // float kernels specialised for these widths use eight pixels per thread (W/8 threads, radix-8
         // passes); every other V = 4 kernel sixteen pixels per thread (W/16 threads)
         // (double kernels of these widths too, with or without injected eigen arrays: row_launch_d)
-        const bool eight = (sizeof(T) == 8 || !p->injected) && (W == 512 || W == 1024 || W == 2048 || W == 4096);
-        rc.threads = eight ? W / 8 : std::min(256, std::max(64, (W / 16 + 63) / 64 * 64));
+        const bool pow2w = W == 512 || W == 1024 || W == 2048 || W == 4096;
+        const bool eight = (sizeof(T) == 8 && pow2w) || (sizeof(T) == 4 && !p->injected && roww_fixed_width(W));
+        rc.threads = eight ? (W / 8 + 63) / 64 * 64 : std::min(256, std::max(64, (W / 16 + 63) / 64 * 64));
         if (!eight && sizeof(T) == 4 && !p->injected) {
             // a row gets more threads (8 or 4 pixels each instead of 16) while the image's rows leave wavefronts for it
             // (eight per CU): a 1000-pixel row on one wavefront takes 74 us, and 1000 rows are half of what the chip holds

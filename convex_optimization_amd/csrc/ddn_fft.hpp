@@ -457,19 +457,47 @@ __device__ __forceinline__ void fft_inverse(cx<T>* lds, int narr, int arr_stride
 }
 
 // ======================================================================================
-// Compile-time specialised transforms for power-of-two lengths.  Same radix schedule as the
-// host's factorize() (so positions agree with the generic code and with stored multipliers), but
-// every radix, stride and shift is a constant: straight-line code, a fraction of the generic
-// kernels' instruction footprint (which overflows the instruction cache).
+// Compile-time specialised transforms: lengths 2^a 3^b 5^c 7^d 11^e 13^f.  For powers of two the radix schedule is
+// the host's factorize() (so positions agree with the generic code and with stored multipliers); every radix, stride
+// and shift is a constant: straight-line code, a fraction of the generic kernels' instruction footprint (which
+// overflows the instruction cache) and none of their index arithmetic.
 // ======================================================================================
 constexpr int ilog2_c(int n) { return n <= 1 ? 0 : 1 + ilog2_c(n >> 1); }
-// Two radix schedules: SCH = 16 (radix-16 first; identical to the host's factorize(), used wherever
-// the digit-reversed order is shared with stored multipliers, i.e. the column transforms) and
+constexpr int pow2_part(int n) {
+    int p = 1;
+    while (n > 1 && n % 2 == 0) {
+        n /= 2;
+        p *= 2;
+    }
+    return p;
+}
+constexpr int kOddRadices[5] = {5, 3, 7, 11, 13};   // passes after the power-of-two ones, in this order
+constexpr int odd_npass(int n) {
+    int c = 0;
+    n /= pow2_part(n);
+    for (int i = 0; i < 5; ++i)
+        while (n % kOddRadices[i] == 0) {
+            n /= kOddRadices[i];
+            ++c;
+        }
+    return c;
+}
+constexpr int odd_radix(int n, int j) {
+    n /= pow2_part(n);
+    for (int i = 0; i < 5; ++i)
+        while (n % kOddRadices[i] == 0) {
+            if (j == 0) return kOddRadices[i];
+            --j;
+            n /= kOddRadices[i];
+        }
+    return 1;
+}
+// Two radix schedules of the power-of-two part 2^t: SCH = 16 (radix-16 first; identical to the host's factorize(),
+// used wherever the digit-reversed order is shared with stored multipliers, i.e. the column transforms) and
 // SCH = 8 (radix-8 first: one butterfly per thread per pass with N/8 threads; row transforms only,
 // whose digit-reversed order never leaves the workgroup).
 template <int SCH>
-constexpr int fixed_npass(int n) {
-    const int t = ilog2_c(n);
+constexpr int p2_npass(int t) {
     if (t == 0) return 0;
     if (SCH == 16) {
         const int a = t / 4, r = t % 4;
@@ -479,8 +507,7 @@ constexpr int fixed_npass(int n) {
     return r == 0 ? a : (r == 2 ? a + 1 : (a >= 1 ? a + 1 : 1));
 }
 template <int SCH>
-constexpr int fixed_radix(int n, int s) {
-    const int t = ilog2_c(n);
+constexpr int p2_radix(int t, int s) {
     if (SCH == 16) {
         const int a = t / 4, r = t % 4;
         if (r == 0) return 16;
@@ -494,11 +521,21 @@ constexpr int fixed_radix(int n, int s) {
     return a >= 1 ? (s < a - 1 ? 8 : 4) : 2;   // 8 ... 8 4 4   (2^1: radix 2)
 }
 template <int SCH>
+constexpr int fixed_npass(int n) { return p2_npass<SCH>(ilog2_c(pow2_part(n))) + odd_npass(n); }
+template <int SCH>
+constexpr int fixed_radix(int n, int s) {
+    const int t = ilog2_c(pow2_part(n)), np = p2_npass<SCH>(t);
+    return s < np ? p2_radix<SCH>(t, s) : odd_radix(n, s - np);
+}
+template <int SCH>
 constexpr int fixed_m(int n, int s) {  // n / (radix[0] * ... * radix[s])
     int m = n;
     for (int i = 0; i <= s; ++i) m /= fixed_radix<SCH>(n, i);
     return m;
 }
+static_assert(fixed_npass<8>(1920) == 5 && fixed_radix<8>(1920, 0) == 8 && fixed_radix<8>(1920, 3) == 5 && fixed_radix<8>(1920, 4) == 3 && fixed_m<8>(1920, 4) == 1,
+              "1920 = 8 x 4 x 4 x 5 x 3");
+static_assert(fixed_npass<16>(4096) == 3 && fixed_radix<16>(4096, 2) == 16 && fixed_npass<8>(512) == 3 && fixed_radix<16>(32768, 3) == 8, "powers of two as before");
 
 template <int N, int SCH>
 __device__ __forceinline__ int pos_of_freq_fixed(int k) {
@@ -506,7 +543,7 @@ __device__ __forceinline__ int pos_of_freq_fixed(int k) {
 #pragma unroll
     for (int s = 0; s < fixed_npass<SCH>(N); ++s) {
         const int r = fixed_radix<SCH>(N, s);
-        pos += (k & (r - 1)) * fixed_m<SCH>(N, s);
+        pos += (k % r) * fixed_m<SCH>(N, s);      // (constants: a mask and a shift for the power-of-two radices)
         k /= r;
     }
     return pos;

@@ -58,6 +58,18 @@ int launch_row_fn(hipStream_t st, K fn, int grid, int threads, size_t lds, const
 // whole row's global loads in registers (PF).  V = 1: any W up to 8192, scalar accesses.
 // (two wavefronts per SIMD: with the whole row's loads held in registers these kernels need ~250 of them; compiled
 // for four per SIMD they kept 0.3-0.5 KB per lane in scratch memory and one 512 x 512 image ran 17 % slower)
+// Row widths with a compile-time transform in the float LDS kernels beside the powers of two (common image widths;
+// every entry costs four kernels of build time).  DDN_ROWW_EXTRA(X) applies X to each.
+#ifndef DDN_ROWW_EXTRA
+#define DDN_ROWW_EXTRA(X) X(640) X(800) X(1000) X(1200) X(1280) X(1440) X(1536) X(1600) X(1920) X(2560) X(3072) X(3840)
+#endif
+inline bool roww_fixed_width(int W) {
+    if (W == 512 || W == 1024 || W == 2048 || W == 4096) return true;
+#define DDN_X(w) if (W == w) return true;
+    DDN_ROWW_EXTRA(DDN_X)
+#undef DDN_X
+    return false;
+}
 #ifndef DDN_ROWW_MINW
 #define DDN_ROWW_MINW 2
 #endif
@@ -117,6 +129,9 @@ int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const R
                 case 1024: return row_launch_w<T, P, 1024>(st, grid, threads, lds, c, a);
                 case 2048: return row_launch_w<T, P, 2048>(st, grid, threads, lds, c, a);
                 case 4096: return row_launch_w<T, P, 4096>(st, grid, threads, lds, c, a);
+#define DDN_X(w) case w: return row_launch_w<T, P, w>(st, grid, threads, lds, c, a);
+                DDN_ROWW_EXTRA(DDN_X)
+#undef DDN_X
                 default: break;
             }
         }
@@ -166,6 +181,9 @@ int cp_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const Ro
                 case 1024: return cp_launch_w<T, 1024>(st, grid, threads, lds, c, a);
                 case 2048: return cp_launch_w<T, 2048>(st, grid, threads, lds, c, a);
                 case 4096: return cp_launch_w<T, 4096>(st, grid, threads, lds, c, a);
+#define DDN_X(w) case w: return cp_launch_w<T, w>(st, grid, threads, lds, c, a);
+                DDN_ROWW_EXTRA(DDN_X)
+#undef DDN_X
                 default: break;
             }
         }

@@ -695,3 +695,17 @@ def test_float64_rows_of_512_to_4096_pixels_vs_oracle(pkg, golden_dir, H, W):
     res = _all_four(pkg, kern, b, stC, stA, stP, N)
     bad = {k: v for k, v in res.items() if not v < 1e-5}
     assert not bad, ("own eigenvalues", res)
+
+
+@pytest.mark.parametrize("H,W", [(16, 640), (16, 800), (18, 1000), (16, 1200), (16, 1280), (16, 1440), (24, 1536), (16, 1600), (16, 1920), (16, 2560),
+                                 (16, 3072), (20, 3840), (1920, 64), (96, 1920)])
+def test_common_widths_with_compile_time_row_transforms_vs_oracle(pkg, golden_dir, monkeypatch, H, W):
+    """Rows of 640 ... 3840 pixels (common image widths, 2^a 3^b 5^c) run the float LDS row kernels with a compile-time
+    mixed-radix transform; heights of 1243 ... 2490 rows take a one-pass column stage on four-column tiles: all four
+    solvers against the oracle, N = 10."""
+    monkeypatch.delenv("DDN_FORCE_WAVE_ROWS", raising=False)
+    from test_gpu_long_rows import _all_four, _problem
+    kern, b, stC, stA, stP = _problem(golden_dir, H, W, "motion15_45", torch.float32)
+    res = _all_four(pkg, kern, b, stC, stA, stP, 10)
+    bad = {k: v for k, v in res.items() if not v < 1e-5}
+    assert not bad, res

@@ -307,7 +307,10 @@ bool choose_col(ddn_plan* p) {
         // image, Mpx-it/s, split / one pass: 1280^2 6.7 k / 12.7 k, 1536^2 7.2 / 14.0, 1920^2 8.6 / 18.4 -- 15.7 with the
         // split's tiles 16 wide -- against 2160^2 11.7 / 11.3 and 2400^2 11.9 / 11.9 with five passes; double 1920^2
         // 10.2 / 11.5).
-        const bool narrow_one_pass = cs >= 0 && (1 << cs) >= minc / 2 && p->fh.npass <= 4;
+        // (five passes in float since the common heights have compile-time column transforms: 1440^2 14.0 k / 16.8 k,
+        // 2160^2 14.5 / 15.2, 2400^2 16.1 / 16.0)
+        static const int one_pass_maxpass = getenv("DDN_ONE_PASS_MAXPASS") ? atoi(getenv("DDN_ONE_PASS_MAXPASS")) : (sizeof(T) == 4 ? 5 : 4);
+        const bool narrow_one_pass = cs >= 0 && (1 << cs) >= minc / 2 && p->fh.npass <= one_pass_maxpass;
         if (!narrow_one_pass && (cs < 0 || (1 << cs) < minc)) {
             // split H = A x B, A the largest factor <= sqrt(H)
             A = 1;
@@ -514,6 +517,19 @@ int launch_col_one(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t 
     static const bool generic_only = getenv("DDN_NO_FIXED_COLS") != nullptr;
     if (!generic_only) {
         if (a.fd.n == 64) return launch_col_fn<T, MODE, 64>(p, a, nblocks, threads, lds);
+        if constexpr (sizeof(T) == 4 && (MODE == COL_RES2 || MODE == COL_MUL || MODE == COL_FWD2 || MODE == COL_FWD)) {
+            // common image heights and their factors: kernels of their own units
+            const void* fn = MODE == COL_RES2 ? col_fixed_res2_f32(a.fd.n) : MODE == COL_MUL ? col_fixed_mul_f32(a.fd.n)
+                           : MODE == COL_FWD2 ? col_fixed_fwd2_f32(a.fd.n) : col_fixed_fwd_f32(a.fd.n);
+            if (fn) {
+                int rc = ensure_lds_attr(fn);
+                if (rc) return rc;
+                TimerScope ts(p, false);
+                void* args[] = {(void*)&a};
+                HIPCHK(hipLaunchKernel(fn, dim3(nblocks), dim3(threads), args, lds, p->stream));
+                return DDN_OK;
+            }
+        }
         if constexpr (sizeof(T) == 4) {
             if (a.fd.n == 256) return launch_col_fn<T, MODE, 256>(p, a, nblocks, threads, lds);
             if (a.fd.n == 128) return launch_col_fn<T, MODE, 128>(p, a, nblocks, threads, lds);

@@ -471,7 +471,7 @@ constexpr int pow2_part(int n) {
     }
     return p;
 }
-constexpr int kOddRadices[5] = {5, 3, 7, 11, 13};   // passes after the power-of-two ones, in this order
+constexpr int kOddRadices[5] = {3, 5, 7, 11, 13};   // passes after the power-of-two ones, in the order of the host's factorize()
 constexpr int odd_npass(int n) {
     int c = 0;
     n /= pow2_part(n);
@@ -533,8 +533,10 @@ constexpr int fixed_m(int n, int s) {  // n / (radix[0] * ... * radix[s])
     for (int i = 0; i <= s; ++i) m /= fixed_radix<SCH>(n, i);
     return m;
 }
-static_assert(fixed_npass<8>(1920) == 5 && fixed_radix<8>(1920, 0) == 8 && fixed_radix<8>(1920, 3) == 5 && fixed_radix<8>(1920, 4) == 3 && fixed_m<8>(1920, 4) == 1,
-              "1920 = 8 x 4 x 4 x 5 x 3");
+static_assert(fixed_npass<8>(1920) == 5 && fixed_radix<8>(1920, 0) == 8 && fixed_radix<8>(1920, 3) == 3 && fixed_radix<8>(1920, 4) == 5 && fixed_m<8>(1920, 4) == 1,
+              "1920 = 8 x 4 x 4 x 3 x 5");
+static_assert(fixed_npass<16>(1920) == 4 && fixed_radix<16>(1920, 0) == 16 && fixed_radix<16>(1920, 1) == 8 && fixed_radix<16>(1920, 2) == 3 && fixed_radix<16>(1920, 3) == 5,
+              "1920 = 16 x 8 x 3 x 5, the host's schedule");
 static_assert(fixed_npass<16>(4096) == 3 && fixed_radix<16>(4096, 2) == 16 && fixed_npass<8>(512) == 3 && fixed_radix<16>(32768, 3) == 8, "powers of two as before");
 
 template <int N, int SCH>

@@ -61,7 +61,8 @@ int launch_row_fn(hipStream_t st, K fn, int grid, int threads, size_t lds, const
 // Row widths with a compile-time transform in the float LDS kernels beside the powers of two (common image widths;
 // every entry costs four kernels of build time).  DDN_ROWW_EXTRA(X) applies X to each.
 #ifndef DDN_ROWW_EXTRA
-#define DDN_ROWW_EXTRA(X) X(640) X(800) X(1000) X(1200) X(1280) X(1440) X(1536) X(1600) X(1920) X(2560) X(3072) X(3840)
+#define DDN_ROWW_EXTRA(X) X(480) X(600) X(640) X(720) X(768) X(800) X(900) X(960) X(1000) X(1080) X(1200) X(1280) X(1440) X(1536) X(1600) \
+    X(1920) X(2000) X(2160) X(2400) X(2560) X(2880) X(3072) X(3200) X(3600) X(3840)
 #endif
 inline bool roww_fixed_width(int W) {
     if (W == 512 || W == 1024 || W == 2048 || W == 4096) return true;
@@ -97,6 +98,12 @@ int wrown_launch(hipStream_t st, int grid, const RowCommon<float>& c, const type
 int wrown_cp_launch(hipStream_t st, int grid, const RowCommon<float>& c, const CpArgs<float>& a);
 // Wave-per-column single-pass column stage (H = 4096, float; ddn_wcol.hpp), in ddn_wcol.hip.
 int wcol_launch(hipStream_t st, int mode, const wcol::Args& a);
+// k_col<float, COL_RES2 / COL_MUL, n> with the compile-time transform of n rows, or null when n is not in the list
+// (ddn_colfix.hpp)
+const void* col_fixed_res2_f32(int n);
+const void* col_fixed_mul_f32(int n);
+const void* col_fixed_fwd2_f32(int n);   // COL_FWD2 / COL_FWD: the short factor of a split column
+const void* col_fixed_fwd_f32(int n);
 // The same for H = 512, 1024, 2048 (several adjacent columns per wavefront; ddn_wcoln.hpp), in ddn_wcoln.hip.
 int wcoln_launch(hipStream_t st, int mode, const wcol::Args& a);
 

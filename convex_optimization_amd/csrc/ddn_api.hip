@@ -499,9 +499,9 @@ inline LossFin no_loss() {
     return lf;
 }
 
-template <typename T, int MODE, int NF>
+template <typename T, int MODE, int NF, bool SMALL = false>
 int launch_col_fn(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t lds) {
-    auto fn = k_col<T, MODE, NF>;
+    auto fn = k_col<T, MODE, NF, SMALL>;
     int rc = ensure_lds_attr((const void*)fn);
     if (rc) return rc;
     TimerScope ts(p, false);
@@ -515,6 +515,14 @@ int launch_col_one(ddn_plan* p, ColArgs<T>& a, int nblocks, int threads, size_t 
     // factors of a 32768-row column (128 x 256) and of a 4096-row column that is split (64 x 64: float64, slab plans);
     // 512 rows in float64 (the 512 x 512 parity configuration)
     static const bool generic_only = getenv("DDN_NO_FIXED_COLS") != nullptr;
+    static const bool no_small = getenv("DDN_NO_SMALL_COLS") != nullptr;
+    // small tiles (at most four elements per thread and array) of a height without a compile-time transform: the variant
+    // that overlaps its global loads (one image, 100^2 ... 700^2: +3-5 %; nothing for the compile-time heights)
+    const bool small = !no_small && threads <= 512 && (a.fd.n << a.lay.cs) <= 4 * threads;
+    if constexpr (sizeof(T) == 4 && (MODE == COL_RES2 || MODE == COL_MUL)) {
+        if (small && (generic_only || !(MODE == COL_RES2 ? col_fixed_res2_f32(a.fd.n) : col_fixed_mul_f32(a.fd.n))) && a.fd.n != 64 && a.fd.n != 128 && a.fd.n != 256)
+            return launch_col_fn<T, MODE, 0, true>(p, a, nblocks, threads, lds);
+    }
     if (!generic_only) {
         if (a.fd.n == 64) return launch_col_fn<T, MODE, 64>(p, a, nblocks, threads, lds);
         if constexpr (sizeof(T) == 4 && (MODE == COL_RES2 || MODE == COL_MUL || MODE == COL_FWD2 || MODE == COL_FWD)) {

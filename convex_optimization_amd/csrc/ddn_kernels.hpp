@@ -327,8 +327,9 @@ struct ColArgs {
 
 // NF > 0: the transform length is NF, with the compile-time radix schedule of ddn_fft.hpp (the same digit order as the
 // run-time one, so stored multipliers agree); NF = 0: any length, run-time schedule.
-template <typename T, int MODE, int NF = 0>
-__global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
+// SMALL: the launch has at most 512 threads and at most four elements per thread and array (small images); see below.
+template <typename T, int MODE, int NF = 0, bool SMALL = false>
+__global__ void __launch_bounds__(SMALL ? 512 : 1024) k_col(ColArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n = a.fd.n, cs = a.lay.cs, C = 1 << cs;
@@ -352,16 +353,22 @@ __global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
         if (s >= 0 && s < a.lf.iter) return;
     }
 
-    const Tw<T> tw = tw_setup(twa, a.tw, n, tid, nt);
     const size_t tbase = ((size_t)plane * a.lay.ntile + tile) * a.lay.H;  // in rows
     const size_t mbase = (size_t)tile * (a.mult_pitch ? a.mult_pitch : a.lay.H);
     const int ka = a.outer ? freq_of_pos(a.fa, seg) : 0;
     // row of the tile -> row of storage
     auto srow = [&](size_t r) -> size_t { return a.rb_extra ? r + (r >> a.rb_shift) * (size_t)a.rb_extra : r; };
     const int total = n << cs;
-    constexpr int UN = 8;  // loads in flight per thread and array
-    for (int i0 = tid; i0 < total; i0 += nt * UN) {
-        cx<T> v0[UN], v1[UN], w[UN];
+    constexpr int UN = SMALL ? 4 : 8;  // loads in flight per thread and array
+    constexpr bool POINTWISE = MODE != COL_FWD && MODE != COL_FWD2;
+    // SMALL: a tile of at most PRE elements per thread (small images, whose workgroups are given that many threads) is
+    // one chunk: its loads are issued before the twiddle table's, and the multipliers of the pointwise stage before the
+    // forward transform, so that the three global-memory latencies of the workgroup overlap instead of following one
+    // another (the multipliers stay in registers across the transform: hence the lower thread bound).
+    constexpr int PRE = 4;
+    constexpr bool one_chunk = SMALL;
+    cx<T> v0[UN], v1[UN], w[UN];
+    auto load_tile = [&](int i0) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = i0 + u * nt;
@@ -373,6 +380,8 @@ __global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
                 if (a.outer & 1) w[u] = a.twH[e * ka];
             }
         }
+    };
+    auto tile_to_lds = [&](int i0) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = i0 + u * nt;
@@ -385,6 +394,54 @@ __global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
                 if (NARR == 2) lds[arr + SW(i)] = v1[u];
             }
         }
+    };
+    auto load_mult = [&](auto& mm, auto& gc, auto& gr, int i0, auto count) {
+#pragma unroll
+        for (int u = 0; u < decltype(count)::value; ++u) {
+            const int i = i0 + u * nt;
+            if (i < total) {
+                const int c = i & (C - 1), e = i >> cs;
+                const size_t gi = ((mbase + (size_t)seg * a.seg_stride + (size_t)e * a.row_stride) << cs) + c;
+                if (MODE != COL_MULR) mm[u] = a.mult[gi];
+                if (MODE != COL_MUL) {
+                    if (a.gcplx) gc[u] = a.gcplx[gi]; else gr[u] = a.greal[gi];
+                }
+            }
+        }
+    };
+    auto pointwise = [&](auto& mm, auto& gc, auto& gr, int i0, auto count) {
+#pragma unroll
+        for (int u = 0; u < decltype(count)::value; ++u) {
+            const int i = i0 + u * nt;
+            if (i < total) {
+                const int li = SW(i);
+                if (MODE == COL_RES2) {
+                    const cx<T> ek = mm[u];
+                    cx<T> U = lds[li] + mulc(lds[arr + li], ek);
+                    if (a.gcplx) U = U * gc[u]; else U = U * gr[u];
+                    lds[li] = U;
+                    lds[arr + li] = ek * U;
+                } else if (MODE == COL_MUL) {
+                    const cx<T> x = lds[li];
+                    lds[li] = (a.conj_mult ? mulc(x, mm[u]) : x * mm[u]) * a.scale;
+                } else {
+                    if (a.gcplx) lds[li] = lds[li] * gc[u]; else lds[li] = lds[li] * gr[u];
+                }
+            }
+        }
+    };
+    cx<T> pmm[SMALL ? PRE : 1], pgc[SMALL ? PRE : 1];
+    T pgr[SMALL ? PRE : 1];
+    if constexpr (one_chunk) load_tile(tid);
+    const Tw<T> tw = tw_setup(twa, a.tw, n, tid, nt);
+    if constexpr (one_chunk) {
+        if (POINTWISE) load_mult(pmm, pgc, pgr, tid, std::integral_constant<int, PRE>());
+        tile_to_lds(tid);
+    } else {
+        for (int i0 = tid; i0 < total; i0 += nt * UN) {
+            load_tile(i0);
+            tile_to_lds(i0);
+        }
     }
     __syncthreads();
     if ((MODE == COL_FWD || MODE == COL_FWD2) && a.dir == 1) {
@@ -392,40 +449,15 @@ __global__ void __launch_bounds__(1024) k_col(ColArgs<T> a) {
     } else {
         fft_fwd<T, NF, 16>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
     }
-    if (MODE != COL_FWD && MODE != COL_FWD2) {
-        for (int i0 = tid; i0 < total; i0 += nt * UN) {
-            cx<T> mm[UN], gc[UN];
-            T gr[UN];
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int i = i0 + u * nt;
-                if (i < total) {
-                    const int c = i & (C - 1), e = i >> cs;
-                    const size_t gi = ((mbase + (size_t)seg * a.seg_stride + (size_t)e * a.row_stride) << cs) + c;
-                    if (MODE != COL_MULR) mm[u] = a.mult[gi];
-                    if (MODE != COL_MUL) {
-                        if (a.gcplx) gc[u] = a.gcplx[gi]; else gr[u] = a.greal[gi];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int i = i0 + u * nt;
-                if (i < total) {
-                    const int li = SW(i);
-                    if (MODE == COL_RES2) {
-                        const cx<T> ek = mm[u];
-                        cx<T> U = lds[li] + mulc(lds[arr + li], ek);
-                        if (a.gcplx) U = U * gc[u]; else U = U * gr[u];
-                        lds[li] = U;
-                        lds[arr + li] = ek * U;
-                    } else if (MODE == COL_MUL) {
-                        const cx<T> x = lds[li];
-                        lds[li] = (a.conj_mult ? mulc(x, mm[u]) : x * mm[u]) * a.scale;
-                    } else {
-                        if (a.gcplx) lds[li] = lds[li] * gc[u]; else lds[li] = lds[li] * gr[u];
-                    }
-                }
+    if (POINTWISE) {
+        if constexpr (one_chunk) {
+            pointwise(pmm, pgc, pgr, tid, std::integral_constant<int, PRE>());
+        } else {
+            for (int i0 = tid; i0 < total; i0 += nt * UN) {
+                cx<T> mm[UN], gc[UN];
+                T gr[UN];
+                load_mult(mm, gc, gr, i0, std::integral_constant<int, UN>());
+                pointwise(mm, gc, gr, i0, std::integral_constant<int, UN>());
             }
         }
         __syncthreads();

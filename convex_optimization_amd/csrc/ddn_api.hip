@@ -690,6 +690,7 @@ int col_stage(ddn_plan* p, int nplanes, const cx<T>* mult, const T* greal, const
 
 struct RowCfg {
     int V, threads, grid;
+    bool dense = false;     // V == 4, float, compile-time width: the variant for several rounds of workgroups per CU (row_launch_w)
     size_t lds;
     bool aligned = false;   // every array of the launch is 16-byte aligned (noted for the split-row pixel kernels)
 };
@@ -768,6 +769,15 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
     // the V = 4 kernels are compiled for two wavefronts per SIMD, eight per CU: as many workgroups as that holds, so
     // that a small image has all its rows in flight
     if (rc.V == 4) per_cu = std::min(per_cu, std::max(1, 512 / rc.threads));
+    rc.dense = false;
+    if (rc.V == 4 && sizeof(T) == 4 && !p->injected && roww_fixed_width(W)) {
+        static const double dense_k = getenv("DDN_ROW_DENSE_K") ? atof(getenv("DDN_ROW_DENSE_K")) : 1.0;
+        const int dense_per_cu = (int)std::min<size_t>(std::max(1, 1024 / rc.threads), kLdsMax / rc.lds);
+        if (dense_per_cu > per_cu && (double)work_items > dense_k * p->num_cu * per_cu) {
+            rc.dense = true;
+            per_cu = dense_per_cu;
+        }
+    }
     rc.grid = std::max(1, std::min(work_items, p->num_cu * per_cu));
     return true;
 }
@@ -846,7 +856,7 @@ int launch_solver_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, con
         la.vec = cfg.aligned && p->W % 4 == 0 ? 4 : 1;
         return long_row_launch<T, P>(p->stream, p->num_cu, la, a);
     }
-    return row_launch<T, P>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.V, c, a);
+    return row_launch<T, P>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.dense ? 5 : cfg.V, c, a);
 }
 
 template <typename T>
@@ -875,7 +885,7 @@ int launch_cp_row(ddn_plan* p, const RowCfg& cfg, const RowCommon<T>& c, const C
         }
         return long_cp_launch<T>(p->stream, p->num_cu, la, a);
     }
-    return cp_launch<T>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.V, c, a);
+    return cp_launch<T>(p->stream, cfg.grid, cfg.threads, cfg.lds, cfg.dense ? 5 : cfg.V, c, a);
 }
 
 template <typename T>

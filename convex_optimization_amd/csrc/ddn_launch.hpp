@@ -74,8 +74,13 @@ inline bool roww_fixed_width(int W) {
 #ifndef DDN_ROWW_MINW
 #define DDN_ROWW_MINW 2
 #endif
+// dense: the image has several rounds of row workgroups per CU -- the variant compiled for four wavefronts per SIMD (128
+// registers, loads issued where they are used) keeps twice the workgroups resident, and one's transform phases
+// overlap another's memory phases (one 3840 x 3840 image, primal DR row launch 0.358 -> 0.266 ms); the two-per-SIMD
+// variant with the whole row's loads in registers is for images whose rows are all in flight at once.
 template <typename T, class P, int WF>
-int row_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCommon<T>& c, const typename P::Args& a) {
+int row_launch_w(hipStream_t st, int grid, int threads, size_t lds, bool dense, const RowCommon<T>& c, const typename P::Args& a) {
+    if (dense) return launch_row_fn(st, k_solver_row<T, P, 4, 2, false, 0, WF, 512, 4>, grid, threads, lds, c, a);
     return launch_row_fn(st, k_solver_row<T, P, 4, 2, false, 1, WF, 512, DDN_ROWW_MINW>, grid, threads, lds, c, a);
 }
 
@@ -119,6 +124,8 @@ int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const R
     if constexpr (sizeof(T) == 4) {
         if (V == 0) return c.W == 4096 ? wrow_launch<P>(st, grid, c, a) : wrown_launch<P>(st, grid, c, a);
     }
+    const bool dense = V == 5;   // V == 5: as 4, with the four-wavefronts-per-SIMD variant of the compile-time-width float kernels
+    if (V == 5) V = 4;
     if (V == 4) {
         if constexpr (sizeof(T) == 8) {
             switch (c.W) {
@@ -132,11 +139,11 @@ int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const R
         if (spec) return launch_row_fn(st, k_solver_row<T, P, 4, 4, true, 0, 0, 256, 2>, grid, threads, lds, c, a);
         if constexpr (sizeof(T) == 4) {
             switch (c.W) {
-                case 512: return row_launch_w<T, P, 512>(st, grid, threads, lds, c, a);
-                case 1024: return row_launch_w<T, P, 1024>(st, grid, threads, lds, c, a);
-                case 2048: return row_launch_w<T, P, 2048>(st, grid, threads, lds, c, a);
-                case 4096: return row_launch_w<T, P, 4096>(st, grid, threads, lds, c, a);
-#define DDN_X(w) case w: return row_launch_w<T, P, w>(st, grid, threads, lds, c, a);
+                case 512: return row_launch_w<T, P, 512>(st, grid, threads, lds, dense, c, a);
+                case 1024: return row_launch_w<T, P, 1024>(st, grid, threads, lds, dense, c, a);
+                case 2048: return row_launch_w<T, P, 2048>(st, grid, threads, lds, dense, c, a);
+                case 4096: return row_launch_w<T, P, 4096>(st, grid, threads, lds, dense, c, a);
+#define DDN_X(w) case w: return row_launch_w<T, P, w>(st, grid, threads, lds, dense, c, a);
                 DDN_ROWW_EXTRA(DDN_X)
 #undef DDN_X
                 default: break;
@@ -155,7 +162,8 @@ int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const R
 }
 
 template <typename T, int WF>
-int cp_launch_w(hipStream_t st, int grid, int threads, size_t lds, const RowCommon<T>& c, const CpArgs<T>& a) {
+int cp_launch_w(hipStream_t st, int grid, int threads, size_t lds, bool dense, const RowCommon<T>& c, const CpArgs<T>& a) {
+    if (dense) return launch_row_fn(st, k_cp_row<T, 4, 2, false, WF, 512, 4>, grid, threads, lds, c, a);
     return launch_row_fn(st, k_cp_row<T, 4, 2, false, WF, 512, DDN_ROWW_MINW>, grid, threads, lds, c, a);
 }
 
@@ -171,6 +179,8 @@ int cp_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const Ro
     if constexpr (sizeof(T) == 4) {
         if (V == 0) return c.W == 4096 ? wrow_cp_launch(st, grid, c, a) : wrown_cp_launch(st, grid, c, a);
     }
+    const bool dense = V == 5;
+    if (V == 5) V = 4;
     if (V == 4) {
         if constexpr (sizeof(T) == 8) {
             switch (c.W) {
@@ -184,11 +194,11 @@ int cp_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const Ro
         if (spec) return launch_row_fn(st, k_cp_row<T, 4, 4, true, 0, 256, 2>, grid, threads, lds, c, a);
         if constexpr (sizeof(T) == 4) {
             switch (c.W) {
-                case 512: return cp_launch_w<T, 512>(st, grid, threads, lds, c, a);
-                case 1024: return cp_launch_w<T, 1024>(st, grid, threads, lds, c, a);
-                case 2048: return cp_launch_w<T, 2048>(st, grid, threads, lds, c, a);
-                case 4096: return cp_launch_w<T, 4096>(st, grid, threads, lds, c, a);
-#define DDN_X(w) case w: return cp_launch_w<T, w>(st, grid, threads, lds, c, a);
+                case 512: return cp_launch_w<T, 512>(st, grid, threads, lds, dense, c, a);
+                case 1024: return cp_launch_w<T, 1024>(st, grid, threads, lds, dense, c, a);
+                case 2048: return cp_launch_w<T, 2048>(st, grid, threads, lds, dense, c, a);
+                case 4096: return cp_launch_w<T, 4096>(st, grid, threads, lds, dense, c, a);
+#define DDN_X(w) case w: return cp_launch_w<T, w>(st, grid, threads, lds, dense, c, a);
                 DDN_ROWW_EXTRA(DDN_X)
 #undef DDN_X
                 default: break;

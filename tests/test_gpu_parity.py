@@ -726,3 +726,17 @@ def test_common_heights_with_compile_time_column_transforms_vs_oracle(pkg, golde
     res = _all_four(pkg, kern, b, stC, stA, stP, 10)
     bad = {k: v for k, v in res.items() if not v < 1e-5}
     assert not bad, res
+
+
+@pytest.mark.parametrize("H,W", [(1100, 640), (1056, 1000), (600, 1920), (1200, 1920), (540, 2160), (288, 3840), (640, 3840)])
+def test_images_with_several_rounds_of_row_workgroups_vs_oracle(pkg, golden_dir, monkeypatch, H, W):
+    """More rows than the chip holds row workgroups at once (two wavefronts per SIMD) switch the compile-time-width float
+    row kernels to the variant built for four wavefronts per SIMD (for Chambolle-Pock, which takes two rows per
+    workgroup, at twice the height): all four solvers against the oracle, N = 10."""
+    monkeypatch.delenv("DDN_FORCE_WAVE_ROWS", raising=False)
+    monkeypatch.delenv("DDN_ROW_DENSE_K", raising=False)
+    from test_gpu_long_rows import _all_four, _problem
+    kern, b, stC, stA, stP = _problem(golden_dir, H, W, "motion15_45", torch.float32)
+    res = _all_four(pkg, kern, b, stC, stA, stP, 10)
+    bad = {k: v for k, v in res.items() if not v < 1e-5}
+    assert not bad, res

@@ -380,6 +380,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--height", type=int, default=0, help="image4096 with another shape: rows of the image (default: --size); --size is then the width")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -444,6 +445,8 @@ def main():
     from convex_optimization_amd.core.blur import create_motion_blur_kernel
 
     H = W = args.size
+    if args.height > 0 and args.config == "image4096":
+        H = args.height
     B = args.batch
     K, Wm = args.steps, args.warmup
     dt = torch.float64 if args.dtype == "f64" else torch.float32

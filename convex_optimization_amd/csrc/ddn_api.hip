@@ -333,17 +333,22 @@ bool choose_col(ddn_plan* p) {
         while ((1 << lim) < p->tune_cols) ++lim;
     } else {
         // Small images on the tile-generic column kernels (one workgroup per tile): with 16-column tiles a 500 x 500
-        // image has 16 workgroups for 256 CUs.  While both half-spectra stay cache-sized (the narrow pieces the row
-        // kernels then write never reach memory as partial lines), narrow the tiles until there is a workgroup per CU.
-        // (Not where a register-resident kernel family applies: those are tied to the wide tiles.  The rule looks at
-        // one image only, so that a batch is solved exactly as its images would be one by one.)
+        // image has 16 workgroups for 256 CUs.  While both half-spectra of an image stay cache-sized (the narrow pieces
+        // the row kernels then write never reach memory as partial lines), narrow the tiles until the plan's images
+        // together have a workgroup for 9/16 of the CUs -- the widest tiles that do: the row kernels pay for narrow
+        // pieces (measured, Mpx-it/s by columns per tile 1 / 2 / 4 / 8 -- 500^2: 5.2 / 5.2 / 4.7 / 4.2 k; 1000^2: 14.6 /
+        // 15.7 / 15.5 / 13.4; 1920 x 1080: 16.5 / 18.6 / 19.7 / 18.6; 1200^2: 15.3 / 16.2 / 16.9 / 14.8; sixteen images
+        // of 1000^2, 2 / 4 / 8 / 16 columns: 28.9 / 34.2 / 34.8 / 34.8).  The tile width changes no arithmetic: a batch
+        // gives the results its images give one by one.
+        // (Not where a register-resident kernel family applies: those are tied to the wide tiles.)
         auto wave_len = [](int n) { return n == 512 || n == 1024 || n == 2048 || n == 4096; };
         const bool wave = sizeof(T) == 4 && (wave_len(H) || wave_len(p->W));
         const size_t spectra = 2 * (size_t)H * p->Wh * sizeof(cx<T>);
         // (nor for a split transform, whose launches have a workgroup per tile AND segment, nor below the 64-byte piece)
         if (!wave && A == 1 && (1 << c2) >= minc && spectra <= ((size_t)32 << 20)) {
             const int cus = p->num_cu > 0 ? p->num_cu : 256;
-            while (lim > 0 && ((p->Wh + (1 << lim) - 1) >> lim) < cus) --lim;
+            const long batch = std::max(1, p->batch);
+            while (lim > 0 && batch * ((p->Wh + (1 << lim) - 1) >> lim) < (long)cus * 9 / 16) --lim;
         }
     }
     p->cs = std::min(c2, lim);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py over a list of image sizes (one image each, every run in its own process): one line per configuration with
 the aggregate rate and, per solver, ms per iteration, row launch, column launch (x launches per iteration) and the
-whole-iteration fraction of the HBM roofline.  usage: tools_sweep_sizes.py out.txt "SIZE [bench args]" ..."""
+whole-iteration fraction of the HBM roofline.  usage: tools_sweep_sizes.py out.txt "SIZE [bench args]" ...  (for H x W: "W --height H")"""
 import json
 import os
 import subprocess

@@ -572,32 +572,150 @@ __device__ __forceinline__ void fixed_pass(cx<T>* lds, int narr, int arr_stride,
     }
 }
 
-template <typename T, int N, int SCH, int S = 0>
-__device__ __forceinline__ void fft_forward_fixed(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, int cshift, int tid, int nt) {
-    if constexpr (S < fixed_npass<SCH>(N)) {
-        fixed_pass<T, N, SCH, S, false>(lds, narr, arr_stride, tw, cshift, tid, nt);
-        __syncthreads();
-        fft_forward_fixed<T, N, SCH, S + 1>(lds, narr, arr_stride, tw, cshift, tid, nt);
+// Two consecutive passes in one: the R1 x R2 elements base + a M1 + b M2 (M1 = R2 M2) go through pass S (R2 butterflies
+// of radix R1 over a) and pass S + 1 (R1 butterflies of radix R2 over b) in registers -- the same butterflies, twiddles
+// and positions as the two passes one after the other, without the trip through the LDS and the barrier between them.
+template <typename T, int N, int SCH, int S, bool INV>
+__device__ __forceinline__ void fixed_pass2(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, int cshift, int tid, int nt) {
+    constexpr int R1 = fixed_radix<SCH>(N, S), R2 = fixed_radix<SCH>(N, S + 1), M1 = fixed_m<SCH>(N, S), M2 = fixed_m<SCH>(N, S + 1);
+    constexpr int TW1 = N / (M1 * R1), TW2 = N / (M2 * R2);
+    static_assert(M1 == R2 * M2, "consecutive passes");
+    const int per = (N / (R1 * R2)) << cshift;
+    const int total = per * narr;
+    for (int w = tid; w < total; w += nt) {
+        int arrn = 0, ww = w;
+        if (narr == 2) {
+            arrn = w >= per ? 1 : 0;
+            ww = w - (arrn ? per : 0);
+        } else if (narr > 2) {
+            arrn = w / per;
+            ww = w - arrn * per;
+        }
+        const int c = ww & ((1 << cshift) - 1);
+        const int bf = ww >> cshift;
+        const int blk = bf / M2, jj2 = bf % M2;
+        const int base = blk * (M1 * R1) + jj2;
+        cx<T>* L = lds + arrn * arr_stride;
+        cx<T> v[R1 * R2];
+        int idx[R1 * R2];
+#pragma unroll
+        for (int a = 0; a < R1; ++a)
+#pragma unroll
+            for (int b = 0; b < R2; ++b) {
+                idx[a * R2 + b] = SW(((base + a * M1 + b * M2) << cshift) + c);
+                v[a * R2 + b] = L[idx[a * R2 + b]];
+            }
+        auto outer = [&]() {     // pass S: radix R1 over a, for every b
+#pragma unroll
+            for (int b = 0; b < R2; ++b) {
+                cx<T> t[R1];
+#pragma unroll
+                for (int a = 0; a < R1; ++a) t[a] = v[a * R2 + b];
+                const int e = (b * M2 + jj2) * TW1;
+                if (INV) {
+#pragma unroll
+                    for (int q = 1; q < R1; ++q) t[q] = mulc(t[q], tw[q * e]);
+                }
+                Dft<T, R1, INV>::run(t);
+                if (!INV) {
+#pragma unroll
+                    for (int q = 1; q < R1; ++q) t[q] = t[q] * tw[q * e];
+                }
+#pragma unroll
+                for (int a = 0; a < R1; ++a) v[a * R2 + b] = t[a];
+            }
+        };
+        auto inner = [&]() {     // pass S + 1: radix R2 over b, for every a
+#pragma unroll
+            for (int a = 0; a < R1; ++a) {
+                cx<T> t[R2];
+#pragma unroll
+                for (int b = 0; b < R2; ++b) t[b] = v[a * R2 + b];
+                const int e = jj2 * TW2;
+                if (INV && M2 > 1) {
+#pragma unroll
+                    for (int q = 1; q < R2; ++q) t[q] = mulc(t[q], tw[q * e]);
+                }
+                Dft<T, R2, INV>::run(t);
+                if (!INV && M2 > 1) {
+#pragma unroll
+                    for (int q = 1; q < R2; ++q) t[q] = t[q] * tw[q * e];
+                }
+#pragma unroll
+                for (int b = 0; b < R2; ++b) v[a * R2 + b] = t[b];
+            }
+        };
+        if (INV) {
+            inner();
+            outer();
+        } else {
+            outer();
+            inner();
+        }
+#pragma unroll
+        for (int i = 0; i < R1 * R2; ++i) L[idx[i]] = v[i];
     }
 }
-template <typename T, int N, int SCH, int S = fixed_npass<SCH>(N) - 1>
+
+// Which passes go in pairs: left to right, a pass joins the next when the product of their radices is at most the
+// caller's limit FUSE and neither is a table-driven prime radix (7, 11, 13).  The column kernels ask for kFuseMax<T>
+// (float: 16 values in registers -- 24 or 25 cost the 128-register column kernels 0.3 KB of scratch; double: none): one 1080 x 1080 image, column launch 34 -> 30 us, sixteen 1920 x 1080
+// images 0.39 -> 0.33 ms.  The row kernels ask for none: their transforms run one radix-8 butterfly per thread, a pair
+// leaves half of the threads idle and, at 128 registers, 0.25 KB of scratch (1920^2 row launch 81 -> 108 us).
+template <typename T>
+constexpr int kFuseMax = sizeof(T) == 4 ? 16 : 0;
+template <int SCH>
+constexpr bool fuse_ok(int n, int s, int lim) {
+    if (s + 1 >= fixed_npass<SCH>(n)) return false;
+    const int r1 = fixed_radix<SCH>(n, s), r2 = fixed_radix<SCH>(n, s + 1);
+    return r1 * r2 <= lim && r1 != 7 && r1 != 11 && r1 != 13 && r2 != 7 && r2 != 11 && r2 != 13;
+}
+// 0: pass s stands alone; 1: s is the first of a pair; 2: s is the second of a pair
+template <int SCH>
+constexpr int fuse_role(int n, int s, int lim) {
+    int i = 0;
+    while (i < fixed_npass<SCH>(n)) {
+        const bool pair = fuse_ok<SCH>(n, i, lim);
+        if (i == s) return pair ? 1 : 0;
+        if (pair && i + 1 == s) return 2;
+        i += pair ? 2 : 1;
+    }
+    return 0;
+}
+static_assert(fuse_role<8>(1920, 0, 16) == 0 && fuse_role<8>(1920, 1, 16) == 1 && fuse_role<8>(1920, 2, 16) == 2 && fuse_role<8>(1920, 3, 16) == 1 &&
+              fuse_role<8>(1920, 4, 16) == 2, "1920 = 8 x (4 x 4) x (3 x 5)");
+static_assert(fuse_role<16>(1080, 0, 16) == 0 && fuse_role<16>(1080, 1, 16) == 1 && fuse_role<16>(1080, 3, 16) == 1, "1080 = 8 x (3 x 3) x (3 x 5)");
+
+template <typename T, int N, int SCH, int FUSE, int S = 0>
+__device__ __forceinline__ void fft_forward_fixed(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, int cshift, int tid, int nt) {
+    if constexpr (S < fixed_npass<SCH>(N)) {
+        constexpr int role = fuse_role<SCH>(N, S, FUSE);
+        if constexpr (role == 1) fixed_pass2<T, N, SCH, S, false>(lds, narr, arr_stride, tw, cshift, tid, nt);
+        else fixed_pass<T, N, SCH, S, false>(lds, narr, arr_stride, tw, cshift, tid, nt);
+        __syncthreads();
+        fft_forward_fixed<T, N, SCH, FUSE, S + (role == 1 ? 2 : 1)>(lds, narr, arr_stride, tw, cshift, tid, nt);
+    }
+}
+template <typename T, int N, int SCH, int FUSE, int S = fixed_npass<SCH>(N) - 1>
 __device__ __forceinline__ void fft_inverse_fixed(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, int cshift, int tid, int nt) {
     if constexpr (S >= 0) {
-        fixed_pass<T, N, SCH, S, true>(lds, narr, arr_stride, tw, cshift, tid, nt);
+        constexpr int role = fuse_role<SCH>(N, S, FUSE);
+        if constexpr (role == 2) fixed_pass2<T, N, SCH, S - 1, true>(lds, narr, arr_stride, tw, cshift, tid, nt);
+        else fixed_pass<T, N, SCH, S, true>(lds, narr, arr_stride, tw, cshift, tid, nt);
         __syncthreads();
-        fft_inverse_fixed<T, N, SCH, S - 1>(lds, narr, arr_stride, tw, cshift, tid, nt);
+        fft_inverse_fixed<T, N, SCH, FUSE, S - (role == 2 ? 2 : 1)>(lds, narr, arr_stride, tw, cshift, tid, nt);
     }
 }
 
 // Dispatchers: NF > 0 selects the specialised code (schedule SCH), NF == 0 the generic run-time schedule.
-template <typename T, int NF, int SCH = 16>
+template <typename T, int NF, int SCH = 16, int FUSE = 0>
 __device__ __forceinline__ void fft_fwd(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int cshift, int tid, int nt) {
-    if constexpr (NF > 0) fft_forward_fixed<T, NF, SCH>(lds, narr, arr_stride, tw, cshift, tid, nt);
+    if constexpr (NF > 0) fft_forward_fixed<T, NF, SCH, FUSE>(lds, narr, arr_stride, tw, cshift, tid, nt);
     else fft_forward<T>(lds, narr, arr_stride, tw, d, cshift, tid, nt);
 }
-template <typename T, int NF, int SCH = 16>
+template <typename T, int NF, int SCH = 16, int FUSE = 0>
 __device__ __forceinline__ void fft_inv(cx<T>* lds, int narr, int arr_stride, const Tw<T>& tw, const FftDesc& d, int cshift, int tid, int nt) {
-    if constexpr (NF > 0) fft_inverse_fixed<T, NF, SCH>(lds, narr, arr_stride, tw, cshift, tid, nt);
+    if constexpr (NF > 0) fft_inverse_fixed<T, NF, SCH, FUSE>(lds, narr, arr_stride, tw, cshift, tid, nt);
     else fft_inverse<T>(lds, narr, arr_stride, tw, d, cshift, tid, nt);
 }
 template <int NF, int SCH = 16>

@@ -445,9 +445,9 @@ __global__ void __launch_bounds__(SMALL ? 512 : 1024) k_col(ColArgs<T> a) {
     }
     __syncthreads();
     if ((MODE == COL_FWD || MODE == COL_FWD2) && a.dir == 1) {
-        fft_inv<T, NF, 16>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
+        fft_inv<T, NF, 16, kFuseMax<T>>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
     } else {
-        fft_fwd<T, NF, 16>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
+        fft_fwd<T, NF, 16, kFuseMax<T>>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
     }
     if (POINTWISE) {
         if constexpr (one_chunk) {
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(SMALL ? 512 : 1024) k_col(ColArgs<T> a) {
             }
         }
         __syncthreads();
-        fft_inv<T, NF, 16>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
+        fft_inv<T, NF, 16, kFuseMax<T>>(lds, NARR, arr, tw, a.fd, cs, tid, nt);
     }
     for (int i = tid; i < total; i += nt) {
         const int c = i & (C - 1), e = i >> cs;

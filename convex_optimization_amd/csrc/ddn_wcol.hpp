@@ -274,7 +274,7 @@ __device__ __forceinline__ void dense_column(const Args& a, int plane, float* ti
         L[(i & ~4095) + SW(i & 4095)] = mk<float>(in[k], 0.f);
     }
     __syncthreads();
-    fft_forward_fixed<float, 4096, 16>(L, NARR, 4096, tw, 0, tid, NT);
+    fft_forward_fixed<float, 4096, 16, 0>(L, NARR, 4096, tw, 0, tid, NT);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const cx<float> e = ev[k];
@@ -291,7 +291,7 @@ __device__ __forceinline__ void dense_column(const Args& a, int plane, float* ti
         }
     }
     __syncthreads();
-    fft_inverse_fixed<float, 4096, 16>(L, NARR, 4096, tw, 0, tid, NT);
+    fft_inverse_fixed<float, 4096, 16, 0>(L, NARR, 4096, tw, 0, tid, NT);
     for (int i = tid; i < NARR * 4096; i += NT) dc[i] = L[(i & ~4095) + SW(i & 4095)].x;
 }
 

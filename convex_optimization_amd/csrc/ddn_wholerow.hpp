@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
         if (consume) {
             spectrum_to_lds<NH, kThreads, kSch>(L, a.c.S0, sr, wW, tid);
             __syncthreads();
-            fft_inverse_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+            fft_inverse_fixed<float, NH, kSch, 0>(L, 1, 0, tw, 0, tid, kThreads);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int p0 = 2 * (tq + kThreads * c);
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
             __syncthreads();
             spectrum_to_lds<NH, kThreads, kSch>(L, a.c.S1, sr, wW, tid);
             __syncthreads();
-            fft_inverse_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+            fft_inverse_fixed<float, NH, kSch, 0>(L, 1, 0, tw, 0, tid, kThreads);
         } else {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
                 if (lane == 63) r = wave < kThreads / 64 - 1 ? sfw[c * 17 + wave + 1] : sfw[((c + 1) % NC) * 17];
                 u[c][3] -= r;
             }
-            fft_forward_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+            fft_forward_fixed<float, NH, kSch, 0>(L, 1, 0, tw, 0, tid, kThreads);
             lds_to_spectrum<NH, kThreads, kSch>(L, a.c.S1, sr, wW, tid);
             __syncthreads();
 #pragma unroll
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
                 L[SW(p0 + 1)] = mk<float>(u[c][2], u[c][3]);
             }
             __syncthreads();
-            fft_forward_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+            fft_forward_fixed<float, NH, kSch, 0>(L, 1, 0, tw, 0, tid, kThreads);
             lds_to_spectrum<NH, kThreads, kSch>(L, a.c.S0, sr, wW, tid);
         }
     }
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
         if (consume) {
             spectrum_to_lds<NH, kThreads, kSch>(L, a.c.S0, sr, wW, tid);
             __syncthreads();
-            fft_inverse_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+            fft_inverse_fixed<float, NH, kSch, 0>(L, 1, 0, tw, 0, tid, kThreads);
         }
         double acc[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(kThreads, kThreads == 256 ? kMinWaves256 : 1) 
         }
         if (produce) {
             __syncthreads();
-            fft_forward_fixed<float, NH, kSch>(L, 1, 0, tw, 0, tid, kThreads);
+            fft_forward_fixed<float, NH, kSch, 0>(L, 1, 0, tw, 0, tid, kThreads);
             lds_to_spectrum<NH, kThreads, kSch>(L, a.c.S0, sr, wW, tid);
         }
     }

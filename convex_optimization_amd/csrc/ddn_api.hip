@@ -1720,7 +1720,7 @@ int static_scratch(double** out) {
 // =============================================================================== C ABI
 extern "C" {
 
-int ddn_version(void) { return 310; }
+int ddn_version(void) { return 320; }
 const char* ddn_last_error(void) { return ddn_err().c_str(); }
 
 static int plan_create_impl(ddn_plan** out, int H, int W, int batch, int dtype, void* stream, bool restricted) {

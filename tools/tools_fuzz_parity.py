@@ -1,7 +1,7 @@
 """Randomised parity sweep: random image shapes from every kernel family's territory, random blur kernels, all four
 solvers for a few iterations against the CPU oracle (fp32, rel-L2 <= 1e-5).  Prints one line per case and a summary;
 exit status 1 when a case fails.  With a third argument "f64": float64 images with the eigenvalue arrays the reference
-would hold (float32-derived complex64) handed in, rel-L2 <= 1e-11.  usage: tools_fuzz_parity.py [cases] [seed] [f64]"""
+would hold (float32-derived complex64) handed in, rel-L2 <= 1e-11.  usage: tools_fuzz_parity.py [cases] [seed] [f64|f32] [mid]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,14 +17,25 @@ TOL = 1e-11 if f64 else 1e-5
 rng = np.random.default_rng(seed)
 small = [16, 24, 32, 34, 48, 51, 56, 64, 77, 80, 91, 96, 100, 104, 128, 143, 200, 256, 300, 500, 512, 1000, 1024]   # (56 ... 143: radices 7, 11, 13)
 large = [2048, 4096] if f64 else [2048, 4096, 8192, 16384, 32768]
+# common photo and video sizes: compile-time mixed-radix rows and columns, split columns from 2560 rows on; paired with
+# each other (images with several rounds of row workgroups) when the fourth argument is "mid"
+mid = [480, 600, 640, 720, 768, 800, 900, 960, 1000, 1080, 1200, 1280, 1440, 1536, 1600, 1920, 2000, 2160, 2400, 2560, 2880, 3072, 3200, 3600, 3840]
+mid_mode = len(sys.argv) > 4 and sys.argv[4] == "mid"
 fails = []
 for case in range(ncases):
-    if rng.random() < 0.45:
+    u = rng.random()
+    if mid_mode:
+        H, W = int(rng.choice(mid)), int(rng.choice(mid))
+        if u < 0.3:
+            H = int(rng.choice([16, 48, 300, 500]))
+        elif u < 0.6:
+            W = int(rng.choice([32, 64, 300, 500]))
+    elif u < 0.45:
         a, b_ = int(rng.choice(large)), int(rng.choice([16, 32, 48, 64]))
         H, W = (a, b_) if rng.random() < 0.5 else (b_, a)
     else:
         H, W = int(rng.choice(small)), int(rng.choice(small))
-    if H * W > (1 << 20):
+    if H * W > ((9 << 19) if mid_mode else (1 << 20)):
         continue
     ktype = rng.choice(["gauss", "motion"])
     if ktype == "gauss":

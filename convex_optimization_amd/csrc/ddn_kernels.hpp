@@ -118,20 +118,54 @@ __device__ __forceinline__ void vstore(T* p, const T (&r)[V]) {
 }
 
 // Sum NS values over the workgroup; result valid in thread 0.  red: LDS scratch of >= 16*NS doubles.
+// One step of a wavefront sum on the data-parallel-primitive path (no LDS crossbar): v + the value the control word
+// routes to this lane, 0 where there is none.  CTRL: row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+// Sum over the wavefront, valid in lane 63: an inclusive scan within each row of 16 lanes, then the row totals carried
+// into the later rows.  (Six dependent steps like a shuffle tree, at a fraction of its latency: the shuffles go through
+// the LDS crossbar -- the four loss sums of a row took 3.3 k cycles of a 33 k-cycle row.)
+__device__ __forceinline__ double wave_sum63(double v) {
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
+    return v;
+}
+
 template <int NS>
 __device__ __forceinline__ void block_reduce(double (&v)[NS], double* red, int tid, int nt) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v[s] += __shfl_down(v[s], off, 64);
-    }
+    for (int s = 0; s < NS; ++s) v[s] = wave_sum63(v[s]);
     const int wave = tid >> 6, lane = tid & 63, nw = (nt + 63) >> 6;
-    if (lane == 0) {
+    if (nw == 1) {
+        // one wavefront: lane 63 hands its sums to thread 0
+        if (lane == 63) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) red[s] = v[s];
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) v[s] = red[s];
+        }
+        __syncthreads();
+        return;
+    }
+    if (lane == 63) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) red[wave * NS + s] = v[s];
     }
     __syncthreads();
     if (tid == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s] = red[s];
         for (int w = 1; w < nw; ++w) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) v[s] += red[w * NS + s];

@@ -528,6 +528,33 @@ def test_batch_equals_loop_of_single_calls(pkg, golden_dir):
         assert np.array_equal(xb[i].numpy(), xi.numpy())
 
 
+def test_batch_with_its_own_tile_width_equals_loop_of_single_calls(pkg, golden_dir):
+    """The column tile width follows the plan's tile count, batch included: six 200 x 300 images get four-column tiles,
+    one of them alone one-column tiles.  The width changes no arithmetic: every solver gives the batch bit for bit what
+    it gives the images one by one."""
+    k = _load(golden_dir, "kernels.npz")
+    kern = k["motion15_45"]
+    torch.manual_seed(5)
+    B, H, W = 6, 200, 300
+    b = torch.rand(B, H, W)
+    xb = pkg.primal_dr_splitting("l1", kern, b, niters=7, loss_function=pkg.core.mse, tol=-1.0)
+    p0 = torch.rand(B, H, W); q0 = torch.rand(3, B, H, W)
+    yb = pkg.primal_dual_dr_splitting(b, kern, niters=7, init_state=(p0, q0), tol=-1.0)
+    stA = tuple(torch.clamp(torch.randn(s), 0, 1) for s in [(B, H, W), (B, H, W), (3, B, H, W), (3, B, H, W)])
+    ab = pkg.admm_solver(b, "l2", kernel=kern, niters=7, tol=-1.0, init_state=stA)
+    stC = (torch.rand(B, H, W), torch.rand(B, H, W), torch.rand(3, B, H, W))
+    cb = pkg.chambolle_pock_solver(b, kern, "l1", t=0.3, s=0.3, max_iter=7, init_state=stC)
+    for i in (0, 3, 5):
+        xi = pkg.primal_dr_splitting("l1", kern, b[i], niters=7, loss_function=pkg.core.mse, tol=-1.0)
+        assert np.array_equal(xb[i].numpy(), xi.numpy())
+        yi = pkg.primal_dual_dr_splitting(b[i], kern, niters=7, init_state=(p0[i], q0[:, i]), tol=-1.0)
+        assert np.array_equal(yb[i].numpy(), yi.numpy())
+        ai = pkg.admm_solver(b[i], "l2", kernel=kern, niters=7, tol=-1.0, init_state=(stA[0][i], stA[1][i], stA[2][:, i], stA[3][:, i]))
+        assert np.array_equal(ab[i].numpy(), ai.numpy())
+        ci = pkg.chambolle_pock_solver(b[i][None], kern, "l1", t=0.3, s=0.3, max_iter=7, init_state=(stC[0][i], stC[1][i], stC[2][:, i]))
+        assert np.array_equal(np.squeeze(cb[i].numpy()), np.squeeze(ci.numpy()))
+
+
 @pytest.mark.parametrize("shape", [(4096, 4096), (1024, 1024), (100, 100), (300, 500), (2048, 512)])
 def test_operator_identities_at_size(pkg, golden_dir, shape):
     """Size-independent properties at full benchmark sizes: adjointness <Kx,y> = <x,K^T y>,

@@ -793,6 +793,23 @@ struct AdmmP {
     }
 };
 
+// XCD-aware order of the rows a launch works through.  A row's piece of a spectral tile is (8 << cs) bytes (float), so
+// 16 >> cs consecutive rows share a 128-byte line; workgroups go to the eight XCDs round-robin by block index, each XCD
+// with an L2 of its own, so consecutive rows on consecutive workgroups make every L2 fetch the whole line for its piece
+// of it.  Within each group of 8 x (rows per line) rows, the rows of a line are dealt to workgroups eight indices apart --
+// the same XCD, resident together.  v: position in launch order (block index + k x grid), n: rows in all; identity when
+// the grid is not a multiple of eight (block index and position then differ modulo 8) and for a last partial group.
+__device__ __forceinline__ int xcd_row(int v, int n, int rpl_shift) {
+    if (rpl_shift <= 0 || (gridDim.x & 7)) return v;
+    const int G = 8 << rpl_shift;
+    const int g0 = v & ~(G - 1);
+    if (g0 + G > n) return v;
+    const int j = v - g0;
+    return g0 + ((j & 7) << rpl_shift) + (j >> 3);
+}
+template <typename T>
+__device__ __forceinline__ int rows_per_line_shift(int cs) { return max(0, (sizeof(T) == 4 ? 4 : 3) - cs); }
+
 // ---------------------------------------------------------------- fused solver row kernel
 // One workgroup per image row (grid-stride over rows).  Per row:
 //   consume: pack (S0, S1) -> inverse transform -> per pixel (u, K u) and D u (2-tap stencil through
@@ -816,7 +833,9 @@ __global__ void __launch_bounds__(MAXT, MINW) k_solver_row(RowCommon<T> c, typen
     constexpr int NH = SPEC ? NG : 1;
     constexpr int KP = (V * NG) / 2 + 1;  // half-spectrum entries per thread when nt = W / (V*NG)
     constexpr int SCH = (V * NG == 8) ? 8 : 16;  // eight pixels per thread: radix-8 passes, one butterfly per thread
-    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int rpl = (c.dbg_mode & 64) ? 0 : rows_per_line_shift<T>(c.lay.cs);
+    for (int vrow = blockIdx.x; vrow < nrows; vrow += gridDim.x) {
+        const int row = xcd_row(vrow, nrows, rpl);
         const int plane = row / c.H;
         if (c.stop && c.stop[plane] >= 0) continue;
         const size_t ro = (size_t)row * W;
@@ -839,7 +858,7 @@ __global__ void __launch_bounds__(MAXT, MINW) k_solver_row(RowCommon<T> c, typen
             }
         }
         __syncthreads();
-#define DDN_STAMP(i) if (c.dbg && tid == 0 && row == (int)blockIdx.x + (int)gridDim.x) c.dbg[blockIdx.x * 16 + (i)] = clock64();
+#define DDN_STAMP(i) if (c.dbg && tid == 0 && vrow == (int)blockIdx.x + (int)gridDim.x) c.dbg[blockIdx.x * 16 + (i)] = clock64();
         DDN_STAMP(0)
         if (c.do_consume) {
             if (SPEC) {
@@ -1007,7 +1026,9 @@ __global__ void __launch_bounds__(MAXT, MINW) k_cp_row(RowCommon<T> c, CpArgs<T>
     constexpr int NH = SPEC ? NG : 1;
     constexpr int KP = (V * NG) / 2 + 1;
     constexpr int SCH = (V * NG == 8) ? 8 : 16;
-    for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
+    const int ppl = (c.dbg_mode & 64) ? 0 : max(0, rows_per_line_shift<T>(c.lay.cs) - 1);   // (a pair is two adjacent rows)
+    for (int vpr = blockIdx.x; vpr < npairs; vpr += gridDim.x) {
+        const int pr = xcd_row(vpr, npairs, ppl);
         const int plane = pr / ppp;
         const int r0 = (pr - plane * ppp) * 2;
         const int nslot = (r0 + 1 < H) ? 2 : 1;

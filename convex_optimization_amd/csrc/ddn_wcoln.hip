@@ -20,9 +20,11 @@ static int wcoln_go1(hipStream_t st, const wcol::Args& a) {
 
 template <int MODE, int R>
 static int wcoln_go(hipStream_t st, const wcol::Args& a) {
-    // groups per workgroup: measured the same within 2 % for H = 512 and 1024; two are 8 % faster for
-    // H = 2048 (16 bytes of a line per group).  DDN_COLN_NP overrides, for measurements.
-    static const int np = getenv("DDN_COLN_NP") ? atoi(getenv("DDN_COLN_NP")) : (R == 32 ? 2 : 1);
+    // groups per workgroup.  Resolvent mode: one and two measured the same within 2-4 % for H = 512 and 1024; two are
+    // 8 % faster for H = 2048 (16 bytes of a line per group).  Multiplier mode (one spectrum: a group's piece of a row
+    // is 8 M bytes, a quarter of a line at H = 1024): two, 6 % faster there (768 planes of 1024^2: 0.574 -> 0.540 ms
+    // per launch; four: 0.534).  DDN_COLN_NP overrides, for measurements.
+    static const int np = getenv("DDN_COLN_NP") ? atoi(getenv("DDN_COLN_NP")) : ((R == 32 || MODE == COL_MUL) ? 2 : 1);
     constexpr int M = 64 / R;
     if (a.rb_extra) {
         // rows stored in per-source blocks (row-slab decomposition): separate spectra, one group per workgroup

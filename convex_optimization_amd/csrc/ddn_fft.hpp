@@ -67,7 +67,16 @@ __device__ __forceinline__ int fast_div(int n, unsigned magic) { return magic ? 
 // Twiddle source exp(-2 pi i e / n), e in [0, n).  Short transforms keep the whole table in LDS; long
 // ones keep two small tables and form w^e = w^(64*(e>>6)) * w^(e&63) with one complex multiply, so
 // that the table does not compete with the data for LDS (a 4096-entry table would halve occupancy).
-#define DDN_TW_DIRECT_MAX 1024
+// (Direct up to 2048 entries, 4096 in the row kernels, whose LDS holds one row: a two-level twiddle is two LDS reads and
+// a complex multiply where a butterfly's own work is a read, a write and a few operations per element, and these
+// kernels are bound by their vector instructions -- one image of 1920^2 28.4 -> 29.9 k Mpx-it/s with 2048.  The column
+// kernels fill the LDS with columns: heights of 2049 ... 2490 rows only fit four at a time beside the small tables.)
+#define DDN_TW_DIRECT_MAX 2048
+#define DDN_TW_DIRECT_ROWS 4096
+// (float rows; a 4096-entry table of doubles beside a 4096-pixel row of doubles leaves no room for what the split-row
+// kernels keep there as well)
+template <typename T>
+__host__ __device__ constexpr int tw_direct_rows() { return sizeof(T) == 4 ? DDN_TW_DIRECT_ROWS : DDN_TW_DIRECT_MAX; }
 template <typename T>
 struct Tw {
     const cx<T>* t1;
@@ -80,12 +89,12 @@ struct Tw {
 };
 __host__ __device__ __forceinline__ int tw_hi_entries(int n) { return ((n - 1) >> 6) + 1; }
 // entries of LDS needed for the twiddles of a length-n transform
-__host__ __device__ __forceinline__ int tw_lds_entries(int n) { return n <= DDN_TW_DIRECT_MAX ? n : tw_hi_entries(n) + 64; }
+__host__ __device__ __forceinline__ int tw_lds_entries(int n, int dmax = DDN_TW_DIRECT_MAX) { return n <= dmax ? n : tw_hi_entries(n) + 64; }
 // Global layout produced by the host: [direct n][hi tw_hi_entries(n)][lo 64].
 template <typename T>
-__device__ __forceinline__ Tw<T> tw_setup(cx<T>* area, const cx<T>* glob, int n, int tid, int nt) {
+__device__ __forceinline__ Tw<T> tw_setup(cx<T>* area, const cx<T>* glob, int n, int tid, int nt, int dmax = DDN_TW_DIRECT_MAX) {
     Tw<T> tw;
-    if (n <= DDN_TW_DIRECT_MAX) {
+    if (n <= dmax) {
         for (int i = tid; i < n; i += nt) area[i] = glob[i];
         tw.t1 = area;
         tw.t2 = area;

@@ -553,13 +553,13 @@ struct RowLds {
     __device__ __forceinline__ RowLds(unsigned char* smem, int W) {
         data = reinterpret_cast<cx<T>*>(smem);
         tw = data + lds_round(W);
-        red = reinterpret_cast<double*>(tw + tw_lds_entries(W));
+        red = reinterpret_cast<double*>(tw + tw_lds_entries(W, tw_direct_rows<T>()));
         edge = reinterpret_cast<T*>(red + 16 * 4);
     }
 };
 template <typename T>
 __host__ __device__ inline size_t row_lds_bytes(int W, int V) {
-    return (size_t)(lds_round(W) + tw_lds_entries(W)) * sizeof(cx<T>) + 16 * 4 * sizeof(double) + (size_t)(W / V + 8) * sizeof(T);
+    return (size_t)(lds_round(W) + tw_lds_entries(W, tw_direct_rows<T>())) * sizeof(cx<T>) + 16 * 4 * sizeof(double) + (size_t)(W / V + 8) * sizeof(T);
 }
 
 // ============================================================ solver policies (one pixel group)
@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(MAXT, MINW) k_solver_row(RowCommon<T> c, typen
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, W = c.W;
     RowLds<T> L(smem, W);
-    const Tw<T> tw = tw_setup(L.tw, c.twW, W, tid, nt);
+    const Tw<T> tw = tw_setup(L.tw, c.twW, W, tid, nt, tw_direct_rows<T>());
     const int nrows = c.batch * c.H;
     constexpr int NH = SPEC ? NG : 1;
     constexpr int KP = (V * NG) / 2 + 1;  // half-spectrum entries per thread when nt = W / (V*NG)
@@ -1020,7 +1020,7 @@ __global__ void __launch_bounds__(MAXT, MINW) k_cp_row(RowCommon<T> c, CpArgs<T>
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, W = c.W, H = c.H;
     RowLds<T> L(smem, W);
-    const Tw<T> tw = tw_setup(L.tw, c.twW, W, tid, nt);
+    const Tw<T> tw = tw_setup(L.tw, c.twW, W, tid, nt, tw_direct_rows<T>());
     const int ppp = (H + 1) >> 1;  // row pairs per image
     const int npairs = c.batch * ppp;
     constexpr int NH = SPEC ? NG : 1;
@@ -1248,7 +1248,7 @@ __global__ void __launch_bounds__(1024) k_rows_r2c(PlainRowArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, W = a.W, H = a.H;
     RowLds<T> L(smem, W);
-    const Tw<T> tw = tw_setup(L.tw, a.twW, W, tid, nt);
+    const Tw<T> tw = tw_setup(L.tw, a.twW, W, tid, nt, tw_direct_rows<T>());
     const int ppp = (H + 1) >> 1, npairs = a.batch * ppp;
     for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const int plane = pr / ppp, r0 = (pr - plane * ppp) * 2;
@@ -1268,7 +1268,7 @@ __global__ void __launch_bounds__(1024) k_rows_c2r(PlainRowArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, W = a.W, H = a.H;
     RowLds<T> L(smem, W);
-    const Tw<T> tw = tw_setup(L.tw, a.twW, W, tid, nt);
+    const Tw<T> tw = tw_setup(L.tw, a.twW, W, tid, nt, tw_direct_rows<T>());
     const int ppp = (H + 1) >> 1, npairs = a.batch * ppp;
     for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const int plane = pr / ppp, r0 = (pr - plane * ppp) * 2;

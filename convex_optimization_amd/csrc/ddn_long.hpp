@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) k_long_inv(LongArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, W = a.c.W, M = a.M, R = a.R, nq = R / 2 + 1;
     RowLds<T> L(smem, M);
-    const Tw<T> tw = tw_setup(L.tw, a.twM, M, tid, nt);
+    const Tw<T> tw = tw_setup(L.tw, a.twM, M, tid, nt, tw_direct_rows<T>());
     const size_t nrows = (size_t)a.c.batch * a.c.H;
     const RowSlot rs = row_slot(a.narr * nq);
     const int q = rs.sub % nq, arr = rs.sub / nq;
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) k_long_fwd(LongArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, nt = blockDim.x, W = a.c.W, M = a.M, R = a.R, nq = R / 2 + 1;
     RowLds<T> L(smem, M);
-    const Tw<T> tw = tw_setup(L.tw, a.twM, M, tid, nt);
+    const Tw<T> tw = tw_setup(L.tw, a.twM, M, tid, nt, tw_direct_rows<T>());
     const size_t nrows = (size_t)a.c.batch * a.c.H;
     const RowSlot rs = row_slot(nq);
     const int q = rs.sub;

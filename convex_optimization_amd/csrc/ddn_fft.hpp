@@ -112,7 +112,13 @@ __device__ __forceinline__ Tw<T> tw_setup(cx<T>* area, const cx<T>* glob, int n,
 // LDS index swizzle: XOR the low five index bits with two higher bit groups so that the strided
 // accesses of the butterfly passes (strides 16, 32, 256, 1024 ... elements) and the
 // digit-reversed gathers spread over the banks.  A bijection on every aligned block of 32.
+#ifdef DDN_SW_ONE_TERM
+// (units whose kernels hold ONE row in the LDS: no access there strides by multiples of 1024 elements, and the second
+// term is two of the five instructions of every LDS index)
+__device__ __forceinline__ int SW(int i) { return i ^ ((i >> 5) & 31); }
+#else
 __device__ __forceinline__ int SW(int i) { return i ^ ((i >> 5) & 31) ^ ((i >> 10) & 31); }
+#endif
 __host__ __device__ __forceinline__ int lds_round(int n) { return (n + 31) & ~31; }
 
 __device__ __forceinline__ int pos_of_freq(const FftDesc& d, int k) {

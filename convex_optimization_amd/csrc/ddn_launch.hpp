@@ -62,7 +62,7 @@ int launch_row_fn(hipStream_t st, K fn, int grid, int threads, size_t lds, const
 // every entry costs four kernels of build time).  DDN_ROWW_EXTRA(X) applies X to each.
 #ifndef DDN_ROWW_EXTRA
 #define DDN_ROWW_EXTRA(X) X(480) X(600) X(640) X(720) X(768) X(800) X(900) X(960) X(1000) X(1080) X(1200) X(1280) X(1440) X(1536) X(1600) \
-    X(1920) X(2000) X(2160) X(2400) X(2560) X(2880) X(3072) X(3200) X(3600) X(3840)
+    X(1920) X(2000) X(2160) X(2400) X(2560) X(2880) X(3000) X(3024) X(3072) X(3200) X(3600) X(3840) X(4000) X(4032)
 #endif
 inline bool roww_fixed_width(int W) {
     if (W == 512 || W == 1024 || W == 2048 || W == 4096) return true;

@@ -726,7 +726,7 @@ def test_float64_rows_of_512_to_4096_pixels_vs_oracle(pkg, golden_dir, H, W):
 
 @pytest.mark.parametrize("H,W", [(16, 640), (16, 800), (18, 1000), (16, 1200), (16, 1280), (16, 1440), (24, 1536), (16, 1600), (16, 1920), (16, 2560),
                                  (16, 3072), (20, 3840), (1920, 64), (96, 1920), (16, 480), (16, 600), (16, 720), (16, 768), (18, 900), (16, 960),
-                                 (16, 1080), (16, 2000), (16, 2160), (16, 2400), (16, 2880), (16, 3200), (16, 3600)])
+                                 (16, 1080), (16, 2000), (16, 2160), (16, 2400), (16, 2880), (16, 3200), (16, 3600), (16, 3000), (16, 3024), (16, 4000), (16, 4032)])
 def test_common_widths_with_compile_time_row_transforms_vs_oracle(pkg, golden_dir, monkeypatch, H, W):
     """Rows of 480 ... 3840 pixels (common image widths, 2^a 3^b 5^c) run the float LDS row kernels with a compile-time
     mixed-radix transform; heights of 1243 ... 2490 rows take a one-pass column stage on four-column tiles: all four
@@ -740,7 +740,7 @@ def test_common_widths_with_compile_time_row_transforms_vs_oracle(pkg, golden_di
 
 
 @pytest.mark.parametrize("H", [480, 600, 640, 720, 768, 800, 900, 960, 1000, 1080, 1200, 1280, 1440, 1536, 1600, 1920, 2000, 2160,
-                               2400, 2560, 2880, 3072, 3200, 3600, 3840])
+                               2400, 2560, 2880, 3072, 3200, 3600, 3840, 3000, 3024, 4000, 4032])
 def test_common_heights_with_compile_time_column_transforms_vs_oracle(pkg, golden_dir, monkeypatch, H):
     """Columns of 480 ... 2160 rows (common image heights) run the tile-generic column kernels with a compile-time
     mixed-radix transform in the resolvent and multiplier modes, while the set-up transforms of the same plan (blur

@@ -741,14 +741,21 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
         rc.V = -1; rc.threads = 256; rc.lds = 0; rc.grid = 1; rc.aligned = aligned;
         return true;
     }
-    if (aligned && W % 4 == 0 && W <= 4096 && fft_min_threads(p->fw) <= 256) {   // (256: the launch bound of the V = 4 kernels)
+    // (float rows of 4097 ... 8192 pixels: the 16-byte-access kernel with 512 threads instead of scalar accesses -- one
+    // 6000 x 4000 image 13.3 k Mpx-it/s before; not with injected eigen arrays, whose kernels are built for 256 threads)
+    // (nor with a radix above 16: the run-time prime pass wants the scalar kernel's thousand threads -- 5472 = 2^5 3^2 19:
+    // 7.0 k against 6.5 k)
+    bool small_radices = true;
+    for (int s = 0; s < p->fw.npass; ++s) small_radices = small_radices && p->fw.radix[s] <= 16;
+    const int vec_max_w = (sizeof(T) == 4 && !p->injected && small_radices) ? 8192 : 4096;
+    if (aligned && W % 4 == 0 && W <= vec_max_w && fft_min_threads(p->fw) <= 256) {   // (256: the launch bound of most V = 4 kernels)
         rc.V = 4;
         // float kernels specialised for these widths use eight pixels per thread (W/8 threads, radix-8
         // passes); every other V = 4 kernel sixteen pixels per thread (W/16 threads)
         // (double kernels of these widths too, with or without injected eigen arrays: row_launch_d)
         const bool pow2w = W == 512 || W == 1024 || W == 2048 || W == 4096;
         const bool eight = (sizeof(T) == 8 && pow2w) || (sizeof(T) == 4 && !p->injected && roww_fixed_width(W));
-        rc.threads = eight ? (W / 8 + 63) / 64 * 64 : std::min(256, std::max(64, (W / 16 + 63) / 64 * 64));
+        rc.threads = eight ? (W / 8 + 63) / 64 * 64 : std::min(W > 4096 ? 512 : 256, std::max(64, ((W + 15) / 16 + 63) / 64 * 64));
         if (!eight && sizeof(T) == 4 && !p->injected) {
             // a row gets more threads (8 or 4 pixels each instead of 16) while the image's rows leave wavefronts for it
             // (eight per CU): a 1000-pixel row on one wavefront takes 74 us, and 1000 rows are half of what the chip holds

@@ -64,6 +64,17 @@ int launch_row_fn(hipStream_t st, K fn, int grid, int threads, size_t lds, const
 #define DDN_ROWW_EXTRA(X) X(480) X(600) X(640) X(720) X(768) X(800) X(900) X(960) X(1000) X(1080) X(1200) X(1280) X(1440) X(1536) X(1600) \
     X(1920) X(2000) X(2160) X(2400) X(2560) X(2880) X(3000) X(3024) X(3072) X(3200) X(3600) X(3840) X(4000) X(4032)
 #endif
+// Float rows of 4097 ... 8192 pixels with a compile-time transform (sixteen pixels per thread, 512 threads): photo and
+// video widths up to 24 megapixels and 8K UHD.
+#ifndef DDN_ROWW_WIDE
+#define DDN_ROWW_WIDE(X) X(4608) X(5120) X(5184) X(6000) X(6144) X(7680) X(8000)
+#endif
+inline bool roww_wide_fixed_width(int W) {
+#define DDN_X(w) if (W == w) return true;
+    DDN_ROWW_WIDE(DDN_X)
+#undef DDN_X
+    return false;
+}
 inline bool roww_fixed_width(int W) {
     if (W == 512 || W == 1024 || W == 2048 || W == 4096) return true;
 #define DDN_X(w) if (W == w) return true;
@@ -155,6 +166,17 @@ int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const R
             if (threads <= 512 && threads * 4 >= c.W) return launch_row_fn(st, k_solver_row<T, P, 4, 1, false, 0, 0, 512, 2>, grid, threads, lds, c, a);
             if (threads <= 512 && threads * 8 >= c.W) return launch_row_fn(st, k_solver_row<T, P, 4, 2, false, 0, 0, 512, 2>, grid, threads, lds, c, a);
         }
+        if constexpr (sizeof(T) == 4) {
+            if (threads > 256) {   // rows of 4097 ... 8192 pixels
+                switch (c.W) {
+#define DDN_X(w) case w: return launch_row_fn(st, k_solver_row<T, P, 4, 4, false, 0, w, 512, 2>, grid, threads, lds, c, a);
+                    DDN_ROWW_WIDE(DDN_X)
+#undef DDN_X
+                    default: break;
+                }
+                return launch_row_fn(st, k_solver_row<T, P, 4, 4, false, 0, 0, 512, 2>, grid, threads, lds, c, a);
+            }
+        }
         return launch_row_fn(st, k_solver_row<T, P, 4, 4, false, 0, 0, 256, 2>, grid, threads, lds, c, a);
     }
     if (spec) return launch_row_fn(st, k_solver_row<T, P, 1, 8, true, 0, 0, 1024, 1>, grid, threads, lds, c, a);
@@ -207,6 +229,17 @@ int cp_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const Ro
         if constexpr (sizeof(T) == 4) {
             if (threads <= 512 && threads * 4 >= c.W) return launch_row_fn(st, k_cp_row<T, 4, 1, false, 0, 512, 2>, grid, threads, lds, c, a);
             if (threads <= 512 && threads * 8 >= c.W) return launch_row_fn(st, k_cp_row<T, 4, 2, false, 0, 512, 2>, grid, threads, lds, c, a);
+        }
+        if constexpr (sizeof(T) == 4) {
+            if (threads > 256) {
+                switch (c.W) {
+#define DDN_X(w) case w: return launch_row_fn(st, k_cp_row<T, 4, 4, false, w, 512, 2>, grid, threads, lds, c, a);
+                    DDN_ROWW_WIDE(DDN_X)
+#undef DDN_X
+                    default: break;
+                }
+                return launch_row_fn(st, k_cp_row<T, 4, 4, false, 0, 512, 2>, grid, threads, lds, c, a);
+            }
         }
         return launch_row_fn(st, k_cp_row<T, 4, 4, false, 0, 256, 2>, grid, threads, lds, c, a);
     }

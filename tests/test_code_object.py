@@ -135,7 +135,8 @@ def test_lds_row_kernels_scratch_budget(kernels):
                 # registers, a few of them parked (measured faster all the same: twice the workgroups resident)
                 assert scratch <= 192 and k[".vgpr_count"] <= 128, (n, scratch, k[".vgpr_count"])
                 continue
-            assert scratch <= (256 if double else 32), (n, scratch)
+            wide_cp = "k_cp_row" in n and wf > 4096       # two rows of 4097 ... 8192 pixels beside radix-16 butterflies
+            assert scratch <= (256 if double or wide_cp else 32), (n, scratch)
             assert k[".vgpr_count"] <= 256, (n, k[".vgpr_count"])
         else:
             seen["generic"] += 1

@@ -767,3 +767,18 @@ def test_images_with_several_rounds_of_row_workgroups_vs_oracle(pkg, golden_dir,
     res = _all_four(pkg, kern, b, stC, stA, stP, 10)
     bad = {k: v for k, v in res.items() if not v < 1e-5}
     assert not bad, res
+
+
+@pytest.mark.parametrize("H,W", [(16, 6000), (18, 5000), (24, 4100), (16, 8188), (16, 5472), (600, 6000), (16, 4608), (16, 5120), (16, 5184), (16, 6144),
+                                 (16, 7680), (16, 8000), (4320, 48), (6000, 32), (8000, 32), (4608, 32)])
+def test_rows_of_4097_to_8192_pixels_on_the_sixteen_byte_kernels_vs_oracle(pkg, golden_dir, monkeypatch, H, W):
+    """Float rows of 4097 ... 8192 pixels whose length is a multiple of four (20- and 24-megapixel photo widths among
+    them) take the 16-byte-access row kernels with 512 threads, seven widths with compile-time transforms; 5472 = 2^5 3^2 19,
+    whose prime pass wants more threads, stays on the scalar-access kernel; heights of 4320 ... 8000 rows split into factors
+    with compile-time transforms: all four solvers against the oracle, N = 10."""
+    monkeypatch.delenv("DDN_FORCE_WAVE_ROWS", raising=False)
+    from test_gpu_long_rows import _all_four, _problem
+    kern, b, stC, stA, stP = _problem(golden_dir, H, W, "motion15_45", torch.float32)
+    res = _all_four(pkg, kern, b, stC, stA, stP, 10)
+    bad = {k: v for k, v in res.items() if not v < 1e-5}
+    assert not bad, res

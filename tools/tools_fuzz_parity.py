@@ -19,7 +19,8 @@ small = [16, 24, 32, 34, 48, 51, 56, 64, 77, 80, 91, 96, 100, 104, 128, 143, 200
 large = [2048, 4096] if f64 else [2048, 4096, 8192, 16384, 32768]
 # common photo and video sizes: compile-time mixed-radix rows and columns, split columns from 2560 rows on; paired with
 # each other (images with several rounds of row workgroups) when the fourth argument is "mid"
-mid = [480, 600, 640, 720, 768, 800, 900, 960, 1000, 1080, 1200, 1280, 1440, 1536, 1600, 1920, 2000, 2160, 2400, 2560, 2880, 3072, 3200, 3600, 3840]
+mid = [480, 600, 640, 720, 768, 800, 900, 960, 1000, 1080, 1200, 1280, 1440, 1536, 1600, 1920, 2000, 2160, 2400, 2560, 2880, 3072, 3200, 3600, 3840,
+       3000, 3024, 4000, 4032, 4320, 4608, 5120, 5184, 5472, 6000, 6144, 7680, 8000]
 mid_mode = len(sys.argv) > 4 and sys.argv[4] == "mid"
 fails = []
 for case in range(ncases):

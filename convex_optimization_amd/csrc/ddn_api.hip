@@ -768,6 +768,8 @@ bool row_cfg(const ddn_plan* p, bool aligned, int work_items, RowCfg& rc, bool c
                 }
             }
         }
+        static const bool wide16 = getenv("DDN_WIDE16") != nullptr;
+        if (!wide16 && sizeof(T) == 4 && W > 4096 && !p->injected && roww_wide_fixed_width(W)) rc.threads = (W / 8 + 63) / 64 * 64;   // (row_launch: eight pixels per thread)
         if (!eight) rc.threads = std::max(rc.threads, fft_min_threads(p->fw));   // at most 256: within the kernels' launch bound
     } else {
         if (W > 8192) return false;

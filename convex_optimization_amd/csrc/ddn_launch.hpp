@@ -64,8 +64,10 @@ int launch_row_fn(hipStream_t st, K fn, int grid, int threads, size_t lds, const
 #define DDN_ROWW_EXTRA(X) X(480) X(600) X(640) X(720) X(768) X(800) X(900) X(960) X(1000) X(1080) X(1200) X(1280) X(1440) X(1536) X(1600) \
     X(1920) X(2000) X(2160) X(2400) X(2560) X(2880) X(3000) X(3024) X(3072) X(3200) X(3600) X(3840) X(4000) X(4032)
 #endif
-// Float rows of 4097 ... 8192 pixels with a compile-time transform (sixteen pixels per thread, 512 threads): photo and
-// video widths up to 24 megapixels and 8K UHD.
+// Float rows of 4097 ... 8192 pixels with a compile-time transform: photo and video widths up to 24 megapixels and 8K
+// UHD.  Eight pixels per thread, up to 1024 threads (128 registers, twelve to sixteen wavefronts per CU), unless
+// DDN_WIDE16 asks for sixteen per thread and 512 threads (256 registers, eight wavefronts: 6000 x 4000 20.8 k against
+// 22.7 k Mpx-it/s).
 #ifndef DDN_ROWW_WIDE
 #define DDN_ROWW_WIDE(X) X(4608) X(5120) X(5184) X(6000) X(6144) X(7680) X(8000)
 #endif
@@ -169,7 +171,8 @@ int row_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const R
         if constexpr (sizeof(T) == 4) {
             if (threads > 256) {   // rows of 4097 ... 8192 pixels
                 switch (c.W) {
-#define DDN_X(w) case w: return launch_row_fn(st, k_solver_row<T, P, 4, 4, false, 0, w, 512, 2>, grid, threads, lds, c, a);
+#define DDN_X(w) case w: return threads > 512 ? launch_row_fn(st, k_solver_row<T, P, 4, 2, false, 0, w, 1024, 1>, grid, threads, lds, c, a) \
+                                      : launch_row_fn(st, k_solver_row<T, P, 4, 4, false, 0, w, 512, 2>, grid, threads, lds, c, a);
                     DDN_ROWW_WIDE(DDN_X)
 #undef DDN_X
                     default: break;
@@ -233,7 +236,8 @@ int cp_launch(hipStream_t st, int grid, int threads, size_t lds, int V, const Ro
         if constexpr (sizeof(T) == 4) {
             if (threads > 256) {
                 switch (c.W) {
-#define DDN_X(w) case w: return launch_row_fn(st, k_cp_row<T, 4, 4, false, w, 512, 2>, grid, threads, lds, c, a);
+#define DDN_X(w) case w: return threads > 512 ? launch_row_fn(st, k_cp_row<T, 4, 2, false, w, 1024, 1>, grid, threads, lds, c, a) \
+                                      : launch_row_fn(st, k_cp_row<T, 4, 4, false, w, 512, 2>, grid, threads, lds, c, a);
                     DDN_ROWW_WIDE(DDN_X)
 #undef DDN_X
                     default: break;
